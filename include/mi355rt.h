@@ -1,0 +1,136 @@
+/* mi355rt.h — C ABI of the MI355X path-tracing renderer (libmi355rt.so).
+ *
+ * Drop-in boundary: these entry points are what an FFI binding of the reference's
+ * `class WebGPURenderer` (src/renderer/WebGPURenderer.ts:7-138) would call; each one
+ * cites the TypeScript method it replaces.  Plain pointers and sizes only.
+ *
+ * Ownership: the caller owns every input array; the callee copies during the call
+ * (queue.writeBuffer semantics, ResourceManager.ts:282,318-320,340-341), so inputs may
+ * be freed or mutated right after return.  The callee owns all device memory.
+ * Threading: one HIP stream per context; calls on one context are not re-entrant;
+ * rt_compute / rt_present only enqueue, rt_sync fences (device.queue.onSubmittedWorkDone).
+ * Errors: int status, 0 = ok, > 0 = informational (e.g. "buffer was reallocated"),
+ * < 0 = failure with rt_last_error(ctx) holding the message.  Like the reference's
+ * passes (RaytracePass.ts:38-46,94; RasterizerPass.ts:55,97; PostProcessPass.ts:32-38,60),
+ * rt_compute / rt_present silently skip (return RT_SKIPPED) while resources are missing.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+  RT_OK = 0,
+  RT_REALLOCATED = 1, /* updateBuffer & co. return `needsRebind` */
+  RT_SKIPPED = 2,     /* pass skipped: resources not ready */
+  RT_ERR_INVALID = -1,
+  RT_ERR_HIP = -2,
+  RT_ERR_NOT_READY = -3,
+  RT_ERR_NO_DEVICE = -4
+};
+
+/* updateBuffer(type, data) kinds — WebGPURenderer.ts:55-60 */
+typedef enum rt_kind {
+  RT_KIND_TOPOLOGY = 0,     /* Uint32Array, 20 u32 per triangle  */
+  RT_KIND_INSTANCE = 1,     /* Float32Array, 36 f32 per instance */
+  RT_KIND_LIGHTS = 2,       /* Uint32Array, 2 u32 per light      */
+  RT_KIND_DRAW_COMMANDS = 3 /* Uint32Array, 4 u32 per instance   */
+} rt_kind;
+
+/* device counters (SURVEY.md §8d "Ray definition") */
+typedef struct rt_counters {
+  uint64_t primary_rays;   /* primary-visibility casts                        */
+  uint64_t extension_rays; /* intersect_tlas calls,        Raytracer.wgsl:732 */
+  uint64_t shadow_rays;    /* intersect_tlas_shadow calls, Raytracer.wgsl:688 */
+  uint64_t nodes_visited;  /* BVH node fetches (TLAS + BLAS)                  */
+  uint64_t tris_tested;    /* hit_triangle_raw calls                          */
+  uint64_t shaded_hits;    /* bounce-loop iterations (one shaded hit each)    */
+} rt_counters;
+
+/* constructor(canvas) + init() — WebGPURenderer.ts:17-32, WebGPUContext.ts:14-36.
+ * Returns NULL when no HIP device / the ordinal is invalid (init() throws there). */
+rt_ctx* rt_create(int device_ordinal);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx); /* ctx may be NULL: error of the last failed rt_create */
+
+/* buildPipeline(depth, spp) — WebGPURenderer.ts:34-39, RaytracePass.ts:18-36
+ * (pipeline-override constants MAX_DEPTH, SPP). */
+int rt_set_pipeline(rt_ctx* ctx, uint32_t max_depth, uint32_t spp);
+
+/* updateScreenSize(w, h) — WebGPURenderer.ts:41-45, ResourceManager.ts:97-142:
+ * (re)allocates render target, G-buffer, accumulation buffer and both history textures. */
+int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* resetAccumulation() — WebGPURenderer.ts:47-49, ResourceManager.ts:144-151 */
+int rt_reset_accum(rt_ctx* ctx);
+
+/* loadTexturesFromWorld(bridge) — WebGPURenderer.ts:51-53, ResourceManager.ts:153-198.
+ * Takes the already decoded + resized 1024x1024 RGBA8 layers (decode/resize is the
+ * browser's job in the reference).  layers == 0 binds the 1x1 white default texture. */
+int rt_upload_textures(rt_ctx* ctx, const uint8_t* rgba, uint32_t layers);
+
+/* updateBuffer(type, data) -> needsRebind — WebGPURenderer.ts:55-60, ResourceManager.ts:230-284 */
+int rt_upload(rt_ctx* ctx, rt_kind kind, const void* data, size_t bytes);
+
+/* updateCombinedGeometry(v, n, uv) -> needsRebind — WebGPURenderer.ts:62-68, ResourceManager.ts:286-323 */
+int rt_upload_geometry(rt_ctx* ctx, const float* pos4, const float* nrm4, const float* uv2, uint32_t vertex_count);
+
+/* updateCombinedBVH(tlas, blas) -> needsRebind — WebGPURenderer.ts:70-72, ResourceManager.ts:325-346 */
+int rt_upload_bvh(rt_ctx* ctx, const float* tlas, uint32_t n_tlas_nodes, const float* blas, uint32_t n_blas_nodes);
+
+/* updateSceneUniforms(cameraData, frameCount, lightCount) — WebGPURenderer.ts:74-80, ResourceManager.ts:359-405 */
+int rt_set_scene(rt_ctx* ctx, const float camera[24], uint32_t frame_count, uint32_t light_count);
+
+/* recreateBindGroup() — WebGPURenderer.ts:82-86.  Nothing to rebind on HIP; kept for call parity. */
+int rt_recreate_bind_group(rt_ctx* ctx);
+
+/* compute(frameCount) — WebGPURenderer.ts:88-102: totalFrames++, frame uniforms (Halton jitter),
+ * primary-visibility pass, path-trace pass.  Enqueues on the context stream. */
+int rt_compute(rt_ctx* ctx, uint32_t frame_count);
+
+/* present() — WebGPURenderer.ts:104-129: post pass -> render target, swap history. */
+int rt_present(rt_ctx* ctx);
+
+/* captureFrame() — WebGPURenderer.ts:131-137, WebGPUContext.ts:38-107: tight RGBA8 rows of the
+ * render target (blocking). cap = capacity of out_rgba in bytes (>= width*height*4). */
+int rt_capture(rt_ctx* ctx, uint8_t* out_rgba, size_t cap);
+
+/* device.queue.onSubmittedWorkDone() — main.ts:115, VideoRecorder.ts:167,293 */
+int rt_sync(rt_ctx* ctx);
+
+/* ---- additions for parity tests, checkpointing and multi-GPU sharding (no reference counterpart) ---- */
+int rt_read_accum(rt_ctx* ctx, float* out_rgba32f, size_t cap_bytes);
+int rt_write_accum(rt_ctx* ctx, const float* in_rgba32f, size_t bytes);
+/* any of the three outputs may be NULL */
+int rt_read_gbuffer(rt_ctx* ctx, uint8_t* albedo_rgba8, float* normal_id_rgba32f, float* depth_f32);
+int rt_read_history(rt_ctx* ctx, uint16_t* out_rgba16f, size_t cap_bytes); /* last written history texture */
+int rt_read_uniforms(rt_ctx* ctx, void* out256);                            /* the 256-byte scene uniform block */
+int rt_get_counters(rt_ctx* ctx, rt_counters* out);                         /* blocking */
+int rt_reset_counters(rt_ctx* ctx);
+/* count nodes/tris/shaded hits too (slower kernel variant); rays are always counted */
+int rt_set_counting(rt_ctx* ctx, int detailed);
+/* Restrict compute() to rows y with (y / stripe_rows) % count == rank (interleaved row stripes).
+ * count <= 1 renders everything.  present() is never sharded. */
+int rt_set_stripes(rt_ctx* ctx, uint32_t stripe_rows, uint32_t rank, uint32_t count);
+/* Raw device pointer of the float4 accumulation buffer (width*height*16 bytes) so the caller
+ * can hand it to a collective (RCCL) without a host round trip. */
+void* rt_accum_device_ptr(rt_ctx* ctx);
+/* Run every subsequent enqueue on a caller-provided hipStream_t (NULL = context's own stream). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+/* Average duration in ms of the path-trace kernel over the launches since the last call
+ * (HIP events recorded on the context stream around each launch); also returns the launch count. */
+int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
+int rt_set_kernel_timing(rt_ctx* ctx, int enabled);
+int rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

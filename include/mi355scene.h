@@ -1,0 +1,68 @@
+/* mi355scene.h — C ABI of the native scene compiler.
+ *
+ * Replaces, for the path-tracing hot path only, the Rust->WASM `World` object of
+ * the reference (rust-shader-tools/src/lib.rs:27-381) whose flat arrays the
+ * TypeScript `WorldBridge` getters hand to the renderer
+ * (src/world-bridge.ts:172-205, shapes in src/worker/protocol.ts:14-44).
+ * Every getter returns a pointer into memory owned by the world, valid until
+ * the next ms_world_update()/ms_world_update_camera()/ms_world_destroy(), plus
+ * the element count in f32/u32 units exactly like World::*_ptr / *_len
+ * (lib.rs:274-345).
+ *
+ * Scene names accepted by ms_world_create (scene/factory.rs:5-13):
+ *   "cornell" (default for unknown names), "mixed", "special", "mesh", "viewer".
+ *   "spheres" is refused: the reference seeds it from rand::rng() (helpers.rs:142-151)
+ *   so it has no reproducible output.
+ * Extensions (not in the reference; BASELINE.json configs 3-5, emitted in the
+ * same bridge layout because World::update cannot express them, lib.rs:196-204):
+ *   "instanced1000", "sponza_like", "glass_blob".
+ */
+#ifndef MI355SCENE_H
+#define MI355SCENE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ms_world ms_world;
+
+/* World::new(scene_name, mesh_obj_source, glb_data) lib.rs:45-102.  obj_source may be
+ * NULL.  glTF/GLB input is out of scope.  Returns NULL on error
+ * (ms_last_error() holds the reason). */
+ms_world* ms_world_create(const char* scene_name, const char* obj_source);
+void ms_world_destroy(ms_world* w);
+const char* ms_last_error(void);
+
+/* World::update(time) lib.rs:149-271: rebuild BLAS + vertices, instances, TLAS,
+ * lights and draw commands. (No animations exist without glTF; time is accepted
+ * for signature parity.) */
+void ms_world_update(ms_world* w, float time);
+/* World::update_camera(width, height) lib.rs:347-352. */
+void ms_world_update_camera(ms_world* w, float width, float height);
+
+/* World::*_ptr()/_len() pairs, lib.rs:274-345. *len = number of f32/u32 elements. */
+const float* ms_world_vertices(const ms_world* w, size_t* len);         /* 4 f32 / vertex  */
+const float* ms_world_normals(const ms_world* w, size_t* len);          /* 4 f32 / vertex  */
+const float* ms_world_uvs(const ms_world* w, size_t* len);              /* 2 f32 / vertex  */
+const uint32_t* ms_world_mesh_topology(const ms_world* w, size_t* len); /* 20 u32 / tri    */
+const float* ms_world_tlas(const ms_world* w, size_t* len);             /* 8 f32 / node    */
+const float* ms_world_blas(const ms_world* w, size_t* len);             /* 8 f32 / node    */
+const float* ms_world_instances(const ms_world* w, size_t* len);        /* 36 f32 / inst   */
+const uint32_t* ms_world_lights(const ms_world* w, size_t* len);        /* 2 u32 / light   */
+const uint32_t* ms_world_draw_commands(const ms_world* w, size_t* len); /* 4 u32 / inst    */
+const float* ms_world_camera(const ms_world* w, size_t* len);           /* 24 f32          */
+
+/* World::get_texture_count lib.rs:355-357.  The reference hands out *encoded*
+ * image bytes that the browser decodes and resizes to 1024x1024
+ * (ResourceManager.ts:153-198).  Decoding is out of scope here; synthetic scenes
+ * provide already-decoded RGBA8 1024x1024 layers instead. */
+size_t ms_world_texture_count(const ms_world* w);
+const uint8_t* ms_world_texture_rgba(const ms_world* w, size_t index); /* 1024*1024*4 bytes */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""Build recipes for the native pieces (explicit compiler invocations, in-tree outputs).
+
+  lib/libmi355scene.so   g++    csrc/scene/scene_compiler.cpp      (host, scene compiler)
+  lib/libmi355rt.so      hipcc  csrc/rt_api.hip (+ kernels)        (gfx950, the C-ABI renderer)
+  node/mi355rt.node      gcc    node/addon.c                       (N-API shim over libmi355rt.so)
+
+Outputs are git-ignored (*.so) but travel to the GPU box with the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(REPO_DIR, "include")
+
+SCENE_LIB = os.path.join(LIB_DIR, "libmi355scene.so")
+RT_LIB = os.path.join(LIB_DIR, "libmi355rt.so")
+NODE_ADDON = os.path.join(PKG_DIR, "node", "mi355rt.node")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the kernels must evaluate the same unfused f32 arithmetic as the oracle
+# (SURVEY.md Appendix A.1 "FMA"); HIP's default would contract a*b+c.
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _glob_sources(root, exts):
+    out = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(d, f))
+    return sorted(out)
+
+
+def _headers():
+    return _glob_sources(INCLUDE, (".h",))
+
+
+def build_scene(force=False):
+    src = os.path.join(CSRC, "scene", "scene_compiler.cpp")
+    deps = [src] + _headers()
+    if not force and _newer(SCENE_LIB, deps):
+        return SCENE_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", SCENE_LIB, src]
+    subprocess.run(cmd, check=True)
+    return SCENE_LIB
+
+
+def build_rt(force=False, extra_flags=()):
+    src = os.path.join(CSRC, "rt_api.hip")
+    deps = _glob_sources(CSRC, (".hip", ".h", ".hpp")) + _headers()
+    if not force and _newer(RT_LIB, deps):
+        return RT_LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError("hipcc not found at %s: the HIP renderer cannot be built" % HIPCC)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-o", RT_LIB, src]
+    subprocess.run(cmd, check=True)
+    return RT_LIB
+
+
+def build_node_addon(force=False):
+    """N-API addon (plain C against /usr/include/node/node_api.h). Optional: skipped when the
+    Node headers are absent."""
+    src = os.path.join(PKG_DIR, "node", "addon.c")
+    hdr = "/usr/include/node/node_api.h"
+    if not os.path.exists(src) or not os.path.exists(hdr):
+        return None
+    if not force and _newer(NODE_ADDON, [src] + _headers()):
+        return NODE_ADDON
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I", "/usr/include/node", "-I", INCLUDE,
+           "-o", NODE_ADDON, src, "-ldl"]
+    subprocess.run(cmd, check=True)
+    return NODE_ADDON
+
+
+def build_all(force=False):
+    out = {"scene": build_scene(force), "rt": build_rt(force)}
+    try:
+        out["node"] = build_node_addon(force)
+    except subprocess.CalledProcessError as e:  # the addon is a convenience, not the product path
+        out["node"] = None
+        out["node_error"] = str(e)
+    return out

@@ -1,0 +1,1236 @@
+// scene_compiler.cpp — native scene compiler behind include/mi355scene.h.
+//
+// Produces the ten flat "bridge" arrays the renderer consumes,
+// following the behaviour of the reference's Rust crate:
+//   geometry assembly   rust-shader-tools/src/geometry.rs, scene/helpers.rs, mesh.rs
+//   procedural scenes   rust-shader-tools/src/scene/procedural.rs
+//   BLAS (binned SAH)   rust-shader-tools/src/bvh/blas.rs
+//   TLAS (median split) rust-shader-tools/src/bvh/tlas.rs
+//   packing             rust-shader-tools/src/rebuilder.rs, lib.rs:149-271
+//   camera              rust-shader-tools/src/scene/camera.rs
+// glam 0.30.9 (un-vendored dependency, Cargo.toml:10-18) supplies Mat4::inverse,
+// from_rotation_y, transform_point3 and Vec3::normalize; their published scalar
+// algorithms are restated in the `linalg` section.
+//
+// Compile with -ffp-contract=off: every expression below is plain IEEE f32.
+
+#include "../../../include/mi355scene.h"
+#include "../../../include/mi355rt_layout.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- linalg
+struct V2 {
+  float x = 0, y = 0;
+};
+struct V3 {
+  float x = 0, y = 0, z = 0;
+  float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline float fmin_nn(float a, float b) { return (b != b || a < b) ? a : b; }  // f32::min
+inline float fmax_nn(float a, float b) { return (b != b || a > b) ? a : b; }  // f32::max
+inline V3 vmin(V3 a, V3 b) { return v3(fmin_nn(a.x, b.x), fmin_nn(a.y, b.y), fmin_nn(a.z, b.z)); }
+inline V3 vmax(V3 a, V3 b) { return v3(fmax_nn(a.x, b.x), fmax_nn(a.y, b.y), fmax_nn(a.z, b.z)); }
+inline float length(V3 a) { return std::sqrt(dot(a, a)); }
+// glam Vec3::normalize = self * (1 / length)
+inline V3 normalize(V3 a) { return a * (1.0f / length(a)); }
+inline V3 normalize_or_zero(V3 a) {
+  float rcp = 1.0f / length(a);
+  if (std::isfinite(rcp) && rcp > 0.0f) return a * rcp;
+  return v3(0, 0, 0);
+}
+inline bool is_nan(V3 a) { return a.x != a.x || a.y != a.y || a.z != a.z; }
+inline float to_radians(float deg) { return deg * (3.14159274101257324219f / 180.0f); }
+
+struct M4 {  // column-major, c[col][row]
+  float c[4][4];
+};
+inline M4 m4_identity() {
+  M4 m{};
+  for (int i = 0; i < 4; i++) m.c[i][i] = 1.0f;
+  return m;
+}
+inline M4 m4_from_scale(V3 s) {
+  M4 m{};
+  m.c[0][0] = s.x;
+  m.c[1][1] = s.y;
+  m.c[2][2] = s.z;
+  m.c[3][3] = 1.0f;
+  return m;
+}
+inline M4 m4_from_translation(V3 t) {
+  M4 m = m4_identity();
+  m.c[3][0] = t.x;
+  m.c[3][1] = t.y;
+  m.c[3][2] = t.z;
+  return m;
+}
+inline M4 m4_from_rotation_y(float angle) {
+  float s = std::sin(angle), c = std::cos(angle);
+  M4 m{};
+  m.c[0][0] = c;
+  m.c[0][2] = -s;
+  m.c[1][1] = 1.0f;
+  m.c[2][0] = s;
+  m.c[2][2] = c;
+  m.c[3][3] = 1.0f;
+  return m;
+}
+inline M4 m4_mul(const M4& a, const M4& b) {
+  M4 r{};
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) {
+      float acc = a.c[0][i] * b.c[j][0];
+      acc = acc + a.c[1][i] * b.c[j][1];
+      acc = acc + a.c[2][i] * b.c[j][2];
+      acc = acc + a.c[3][i] * b.c[j][3];
+      r.c[j][i] = acc;
+    }
+  return r;
+}
+inline V3 m4_transform_point3(const M4& m, V3 p) {
+  float r[3];
+  for (int i = 0; i < 3; i++) {
+    float acc = m.c[0][i] * p.x;
+    acc = m.c[1][i] * p.y + acc;
+    acc = m.c[2][i] * p.z + acc;
+    acc = m.c[3][i] + acc;
+    r[i] = acc;
+  }
+  return v3(r[0], r[1], r[2]);
+}
+// General 4x4 inverse by 2x2 sub-determinant factors (the GLM/glam scalar path).
+M4 m4_inverse(const M4& m) {
+  const float m00 = m.c[0][0], m01 = m.c[0][1], m02 = m.c[0][2], m03 = m.c[0][3];
+  const float m10 = m.c[1][0], m11 = m.c[1][1], m12 = m.c[1][2], m13 = m.c[1][3];
+  const float m20 = m.c[2][0], m21 = m.c[2][1], m22 = m.c[2][2], m23 = m.c[2][3];
+  const float m30 = m.c[3][0], m31 = m.c[3][1], m32 = m.c[3][2], m33 = m.c[3][3];
+  const float f[6][4] = {
+      {m22 * m33 - m32 * m23, m22 * m33 - m32 * m23, m12 * m33 - m32 * m13, m12 * m23 - m22 * m13},
+      {m21 * m33 - m31 * m23, m21 * m33 - m31 * m23, m11 * m33 - m31 * m13, m11 * m23 - m21 * m13},
+      {m21 * m32 - m31 * m22, m21 * m32 - m31 * m22, m11 * m32 - m31 * m12, m11 * m22 - m21 * m12},
+      {m20 * m33 - m30 * m23, m20 * m33 - m30 * m23, m10 * m33 - m30 * m13, m10 * m23 - m20 * m13},
+      {m20 * m32 - m30 * m22, m20 * m32 - m30 * m22, m10 * m32 - m30 * m12, m10 * m22 - m20 * m12},
+      {m20 * m31 - m30 * m21, m20 * m31 - m30 * m21, m10 * m31 - m30 * m11, m10 * m21 - m20 * m11}};
+  const float v[4][4] = {{m10, m00, m00, m00}, {m11, m01, m01, m01}, {m12, m02, m02, m02}, {m13, m03, m03, m03}};
+  const float sa[4] = {1.0f, -1.0f, 1.0f, -1.0f};
+  const float sb[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+  M4 inv{};
+  for (int k = 0; k < 4; k++) {
+    inv.c[0][k] = ((v[1][k] * f[0][k] - v[2][k] * f[1][k]) + v[3][k] * f[2][k]) * sa[k];
+    inv.c[1][k] = ((v[0][k] * f[0][k] - v[2][k] * f[3][k]) + v[3][k] * f[4][k]) * sb[k];
+    inv.c[2][k] = ((v[0][k] * f[1][k] - v[1][k] * f[3][k]) + v[3][k] * f[5][k]) * sa[k];
+    inv.c[3][k] = ((v[0][k] * f[2][k] - v[1][k] * f[4][k]) + v[2][k] * f[5][k]) * sb[k];
+  }
+  const float d0 = m00 * inv.c[0][0], d1 = m01 * inv.c[1][0], d2 = m02 * inv.c[2][0], d3 = m03 * inv.c[3][0];
+  const float det = d0 + d1 + d2 + d3;
+  const float rcp = 1.0f / det;
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) inv.c[j][i] = inv.c[j][i] * rcp;
+  return inv;
+}
+
+// ------------------------------------------------------------------ AABB
+struct Aabb {  // primitives.rs:6-76
+  V3 mn = v3(INFINITY, INFINITY, INFINITY);
+  V3 mx = v3(-INFINITY, -INFINITY, -INFINITY);
+};
+inline Aabb aabb_union(const Aabb& a, const Aabb& b) { return Aabb{vmin(a.mn, b.mn), vmax(a.mx, b.mx)}; }
+inline float aabb_area(const Aabb& a) {
+  V3 d = a.mx - a.mn;
+  if (d.x < 0.0f || d.y < 0.0f || d.z < 0.0f) return 0.0f;
+  return 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x);
+}
+inline V3 aabb_center(const Aabb& a) { return (a.mn + a.mx) * 0.5f; }
+Aabb aabb_transform(const Aabb& a, const M4& m) {
+  Aabb out;
+  for (int k = 0; k < 8; k++) {
+    V3 p = v3((k & 1) ? a.mx.x : a.mn.x, (k & 2) ? a.mx.y : a.mn.y, (k & 4) ? a.mx.z : a.mn.z);
+    V3 tp = m4_transform_point3(m, p);
+    out.mn = vmin(out.mn, tp);
+    out.mx = vmax(out.mx, tp);
+  }
+  return out;
+}
+
+// -------------------------------------------------------------- materials
+enum : uint32_t { LAMBERTIAN = 0, METAL = 1, DIELECTRIC = 2, LIGHT = 3 };  // scene/material.rs
+
+// ------------------------------------------------------------------ mesh
+struct ObjMesh {  // mesh.rs:4-9
+  std::vector<V3> vertices, normals;
+  std::vector<V2> uvs;
+  std::vector<uint32_t> indices;
+};
+
+std::vector<std::string> split_ws(const std::string& s) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < s.size()) {
+    while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    size_t j = i;
+    while (j < s.size() && !isspace((unsigned char)s[j])) j++;
+    if (j > i) out.push_back(s.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+float parse_f32_or_zero(const std::string& s) {
+  char* end = nullptr;
+  float v = std::strtof(s.c_str(), &end);
+  if (end == s.c_str() || *end != '\0') return 0.0f;
+  return v;
+}
+// parse::<usize>().unwrap_or(0).saturating_sub(1)
+size_t parse_index(const std::string& s) {
+  size_t b = (!s.empty() && s[0] == '+') ? 1 : 0;
+  if (b >= s.size()) return 0;
+  for (size_t i = b; i < s.size(); i++)
+    if (s[i] < '0' || s[i] > '9') return 0;
+  unsigned long long v = std::strtoull(s.c_str() + b, nullptr, 10);
+  return v == 0 ? 0 : (size_t)(v - 1);
+}
+
+// Wavefront OBJ subset: v / vt / vn / f with p, p/t, p//n, p/t/n; polygons are fan-
+// triangulated; (p,t,n) triples are de-duplicated in first-seen order (mesh.rs:12-124).
+ObjMesh parse_obj(const std::string& source) {
+  ObjMesh mesh;
+  std::vector<V3> raw_p, raw_n;
+  std::vector<V2> raw_t;
+  struct Key {
+    size_t p;
+    long t, n;  // -1 = absent
+  };
+  std::vector<Key> unique;
+  size_t pos = 0;
+  while (pos <= source.size()) {
+    size_t eol = source.find('\n', pos);
+    if (eol == std::string::npos) eol = source.size();
+    std::string line = source.substr(pos, eol - pos);
+    pos = eol + 1;
+    std::vector<std::string> parts = split_ws(line);
+    if (parts.empty()) {
+      if (eol == source.size()) break;
+      continue;
+    }
+    const std::string& tag = parts[0];
+    if (tag == "v" && parts.size() >= 4) {
+      raw_p.push_back(v3(parse_f32_or_zero(parts[1]), parse_f32_or_zero(parts[2]), parse_f32_or_zero(parts[3])));
+    } else if (tag == "vt" && parts.size() >= 3) {
+      raw_t.push_back(V2{parse_f32_or_zero(parts[1]), parse_f32_or_zero(parts[2])});
+    } else if (tag == "vn" && parts.size() >= 4) {
+      raw_n.push_back(v3(parse_f32_or_zero(parts[1]), parse_f32_or_zero(parts[2]), parse_f32_or_zero(parts[3])));
+    } else if (tag == "f") {
+      std::vector<uint32_t> face;
+      for (size_t k = 1; k < parts.size(); k++) {
+        std::vector<std::string> segs;
+        {
+          size_t a = 0;
+          const std::string& s = parts[k];
+          while (true) {
+            size_t b = s.find('/', a);
+            if (b == std::string::npos) {
+              segs.push_back(s.substr(a));
+              break;
+            }
+            segs.push_back(s.substr(a, b - a));
+            a = b + 1;
+          }
+        }
+        Key key;
+        key.p = parse_index(segs[0]);
+        key.t = (segs.size() > 1 && !segs[1].empty()) ? (long)parse_index(segs[1]) : -1;
+        key.n = (segs.size() > 2 && !segs[2].empty()) ? (long)parse_index(segs[2]) : -1;
+        long found = -1;
+        for (size_t u = 0; u < unique.size(); u++)
+          if (unique[u].p == key.p && unique[u].t == key.t && unique[u].n == key.n) {
+            found = (long)u;
+            break;
+          }
+        if (found >= 0) {
+          face.push_back((uint32_t)found);
+          continue;
+        }
+        uint32_t idx = (uint32_t)unique.size();
+        unique.push_back(key);
+        mesh.vertices.push_back(key.p < raw_p.size() ? raw_p[key.p] : v3(0, 0, 0));
+        mesh.uvs.push_back((key.t >= 0 && (size_t)key.t < raw_t.size()) ? raw_t[(size_t)key.t] : V2{0, 0});
+        mesh.normals.push_back((key.n >= 0 && (size_t)key.n < raw_n.size()) ? raw_n[(size_t)key.n] : v3(0, 1, 0));
+        face.push_back(idx);
+      }
+      for (size_t i = 1; i + 1 < face.size(); i++) {
+        mesh.indices.push_back(face[0]);
+        mesh.indices.push_back(face[i]);
+        mesh.indices.push_back(face[i + 1]);
+      }
+    }
+    if (eol == source.size()) break;
+  }
+  return mesh;
+}
+
+// -------------------------------------------------------------- geometry
+struct Geometry {  // geometry.rs:6-25 (skinning fields dropped: no glTF input)
+  std::vector<V3> positions, normals;
+  std::vector<V2> uvs;
+  std::vector<uint32_t> indices;
+  std::vector<float> attributes;  // 16 f32 per triangle
+
+  uint32_t push_vertex(V3 p, V3 n, V2 uv) {
+    positions.push_back(p);
+    normals.push_back(n);
+    uvs.push_back(uv);
+    return (uint32_t)positions.size() - 1;
+  }
+  // geometry.rs:68-103
+  void push_attributes(V3 base, uint32_t mat, float metallic, float roughness, float ior, V3 emissive,
+                       const float tex[4], float occlusion_tex) {
+    const float a[16] = {base.x, base.y, base.z, (float)mat, metallic, roughness, ior, 0.0f,
+                         tex[0], tex[1], tex[2], tex[3], emissive.x, emissive.y, emissive.z, occlusion_tex};
+    attributes.insert(attributes.end(), a, a + 16);
+  }
+  void push_simple_attributes(V3 color, uint32_t mat, float extra, float texture_index) {
+    float metallic = 0.0f, roughness = 1.0f, ior = 1.5f;  // LAMBERTIAN / LIGHT
+    if (mat == METAL) {
+      metallic = 1.0f;
+      roughness = extra;
+    } else if (mat == DIELECTRIC) {
+      roughness = 0.0f;
+      ior = extra;
+    }
+    const float tex[4] = {texture_index, -1.0f, -1.0f, -1.0f};
+    push_attributes(color, mat, metallic, roughness, ior, v3(0, 0, 0), tex, -1.0f);
+  }
+};
+
+// scene/helpers.rs:6-54
+void add_quad(Geometry& g, V3 a, V3 b, V3 c, V3 d, V3 color, uint32_t mat, float extra, float tex) {
+  V3 n = normalize(cross(b - a, d - a));
+  uint32_t i0 = g.push_vertex(a, n, V2{0, 0});
+  uint32_t i1 = g.push_vertex(b, n, V2{1, 0});
+  uint32_t i2 = g.push_vertex(c, n, V2{1, 1});
+  uint32_t i3 = g.push_vertex(d, n, V2{0, 1});
+  const uint32_t t0[3] = {i0, i1, i2}, t1[3] = {i0, i2, i3};
+  g.indices.insert(g.indices.end(), t0, t0 + 3);
+  g.push_simple_attributes(color, mat, extra, tex);
+  g.indices.insert(g.indices.end(), t1, t1 + 3);
+  g.push_simple_attributes(color, mat, extra, tex);
+}
+
+// scene/helpers.rs:56-151 — faces in the order front, back, top, bottom, right, left
+void add_box(Geometry& g, V3 size, V3 center, float rot_y_deg, V3 color, uint32_t mat, float extra, float tex) {
+  float rad = to_radians(rot_y_deg);
+  float cr = std::cos(rad), sr = std::sin(rad);
+  auto tf = [&](V3 p) {
+    float x = p.x * cr + p.z * sr;
+    float z = -p.x * sr + p.z * cr;
+    return v3(x, p.y, z) + center;
+  };
+  V3 dx = v3(size.x / 2.0f, 0, 0), dy = v3(0, size.y / 2.0f, 0), dz = v3(0, 0, size.z / 2.0f);
+  V3 nx = -dx;
+  add_quad(g, tf(nx - dy + dz), tf(dx - dy + dz), tf(dx + dy + dz), tf(nx + dy + dz), color, mat, extra, tex);
+  add_quad(g, tf(dx - dy - dz), tf(nx - dy - dz), tf(nx + dy - dz), tf(dx + dy - dz), color, mat, extra, tex);
+  add_quad(g, tf(nx + dy + dz), tf(dx + dy + dz), tf(dx + dy - dz), tf(nx + dy - dz), color, mat, extra, tex);
+  add_quad(g, tf(nx - dy - dz), tf(dx - dy - dz), tf(dx - dy + dz), tf(nx - dy + dz), color, mat, extra, tex);
+  add_quad(g, tf(dx - dy + dz), tf(dx - dy - dz), tf(dx + dy - dz), tf(dx + dy + dz), color, mat, extra, tex);
+  add_quad(g, tf(nx - dy - dz), tf(nx - dy + dz), tf(nx + dy + dz), tf(nx + dy - dz), color, mat, extra, tex);
+}
+
+// geometry.rs:204-275 — UV sphere, 24 sectors x 12 stacks
+void add_sphere(Geometry& g, V3 center, float radius, V3 color, uint32_t mat, float extra, float tex) {
+  const uint32_t sectors = 24, stacks = 12;
+  const float PI = 3.14159274101257324219f;
+  uint32_t start = (uint32_t)g.positions.size();
+  for (uint32_t i = 0; i <= stacks; i++) {
+    float vc = (float)i / (float)stacks;
+    float stack_angle = PI / 2.0f - PI * vc;
+    float xy = radius * std::cos(stack_angle);
+    float z = radius * std::sin(stack_angle);
+    for (uint32_t j = 0; j <= sectors; j++) {
+      float uc = (float)j / (float)sectors;
+      float sector_angle = 2.0f * PI * uc;
+      float x = xy * std::cos(sector_angle);
+      float y = xy * std::sin(sector_angle);
+      g.push_vertex(v3(x, y, z) + center, normalize(v3(x, y, z)), V2{uc, vc});
+    }
+  }
+  for (uint32_t i = 0; i < stacks; i++) {
+    uint32_t k1 = start + i * (sectors + 1);
+    uint32_t k2 = k1 + sectors + 1;
+    for (uint32_t j = 0; j < sectors; j++) {
+      if (i != 0) {
+        const uint32_t t[3] = {k1 + j, k2 + j, k1 + j + 1};
+        g.indices.insert(g.indices.end(), t, t + 3);
+        g.push_simple_attributes(color, mat, extra, tex);
+      }
+      if (i != stacks - 1) {
+        const uint32_t t[3] = {k1 + j + 1, k2 + j, k2 + j + 1};
+        g.indices.insert(g.indices.end(), t, t + 3);
+        g.push_simple_attributes(color, mat, extra, tex);
+      }
+    }
+  }
+}
+
+// geometry.rs:277-327
+void add_mesh_instance(Geometry& g, const ObjMesh& mesh, V3 pos, float scale, float rot_y_deg, V3 color,
+                       uint32_t mat, float extra, float tex) {
+  if (mesh.vertices.empty()) return;
+  float rad = to_radians(rot_y_deg);
+  float s = std::sin(rad), c = std::cos(rad);
+  // Mat3::from_rotation_y: columns (c,0,-s), (0,1,0), (s,0,c); M*v = col0*v.x + col1*v.y + col2*v.z
+  auto rot = [&](V3 v) {
+    V3 r = v3(c * v.x, 0.0f * v.x, -s * v.x);
+    r = r + v3(0.0f * v.y, 1.0f * v.y, 0.0f * v.y);
+    r = r + v3(s * v.z, 0.0f * v.z, c * v.z);
+    return r;
+  };
+  uint32_t start = (uint32_t)g.positions.size();
+  for (size_t i = 0; i < mesh.vertices.size(); i++) {
+    V3 tv = rot(mesh.vertices[i] * scale) + pos;
+    V3 tn = i < mesh.normals.size() ? rot(mesh.normals[i]) : v3(0, 1, 0);
+    V2 uv = i < mesh.uvs.size() ? mesh.uvs[i] : V2{0, 0};
+    g.push_vertex(tv, tn, uv);
+  }
+  for (size_t k = 0; k + 2 < mesh.indices.size(); k += 3) {
+    g.indices.push_back(mesh.indices[k] + start);
+    g.indices.push_back(mesh.indices[k + 1] + start);
+    g.indices.push_back(mesh.indices[k + 2] + start);
+    g.push_simple_attributes(color, mat, extra, tex);
+  }
+}
+
+// geometry.rs:105-131 / 133-166 (used by `cornell` + OBJ, kept for completeness)
+Geometry geometry_from_mesh(const ObjMesh& mesh) {
+  Geometry g;
+  for (size_t i = 0; i < mesh.vertices.size(); i++)
+    g.push_vertex(mesh.vertices[i], i < mesh.normals.size() ? mesh.normals[i] : v3(0, 1, 0),
+                  i < mesh.uvs.size() ? mesh.uvs[i] : V2{0, 0});
+  const float notex[4] = {-1, -1, -1, -1};
+  for (size_t k = 0; k + 2 < mesh.indices.size(); k += 3) {
+    g.indices.insert(g.indices.end(), mesh.indices.begin() + k, mesh.indices.begin() + k + 3);
+    g.push_attributes(v3(1, 1, 1), LAMBERTIAN, 0.0f, 1.0f, 1.5f, v3(0, 0, 0), notex, -1.0f);
+  }
+  return g;
+}
+
+// ----------------------------------------------------------------- scene
+struct CameraConfig {  // scene/camera.rs:3-11
+  V3 lookfrom, lookat, vup;
+  float vfov = 60, defocus_angle = 0, focus_dist = 1;
+};
+struct SceneInstance {
+  M4 transform;
+  size_t geometry_index;
+};
+struct SceneData {
+  CameraConfig camera;
+  std::vector<Geometry> geometries;
+  std::vector<SceneInstance> instances;
+  std::vector<std::vector<uint8_t>> textures_rgba;  // decoded 1024x1024 RGBA8 layers (synthetic scenes only)
+  bool keep_instance_transforms = false;            // synthetic scenes bypass lib.rs:196-204
+};
+
+// scene/camera.rs:14-56
+void camera_buffer(const CameraConfig& c, float aspect, float out[24]) {
+  float theta = to_radians(c.vfov);
+  float h = std::tan(theta / 2.0f);
+  float vh = 2.0f * h * c.focus_dist;
+  float vw = vh * aspect;
+  V3 w = normalize(c.lookfrom - c.lookat);
+  V3 u = normalize(cross(c.vup, w));
+  V3 v = cross(w, u);
+  V3 horizontal = u * vw;
+  V3 vertical = v * vh;
+  V3 ll = c.lookfrom - horizontal * 0.5f - vertical * 0.5f - w * c.focus_dist;
+  float lens_radius = c.focus_dist * std::tan(to_radians(c.defocus_angle) / 2.0f);
+  const float buf[24] = {c.lookfrom.x, c.lookfrom.y, c.lookfrom.z, lens_radius, ll.x, ll.y, ll.z, 0.0f,
+                         horizontal.x, horizontal.y, horizontal.z, 0.0f, vertical.x, vertical.y, vertical.z, 0.0f,
+                         u.x, u.y, u.z, 0.0f, v.x, v.y, v.z, 0.0f};
+  std::memcpy(out, buf, sizeof(buf));
+}
+
+// Cornell coordinate maps, procedural.rs:23-25
+inline V3 cb_v(float x, float y, float z) {
+  const float s = 555.0f;
+  return v3(x / s * 2.0f - 1.0f, y / s * 2.0f, z / s * 2.0f - 1.0f);
+}
+inline V3 cb_sz(float x, float y, float z) {
+  const float s = 555.0f;
+  return v3(x / s * 2.0f, y / s * 2.0f, z / s * 2.0f);
+}
+
+struct CornellStyle {
+  uint32_t floor_mat;
+  float floor_extra;
+  V3 light_color;
+  float lx0, lz0, lx1, lz1;
+};
+// The five walls + ceiling light shared by cornell / special / viewer
+// (procedural.rs:27-96, 388-459, 641-720).
+void add_cornell_shell(Geometry& g, const CornellStyle& st) {
+  V3 white = v3(0.73f, 0.73f, 0.73f), red = v3(0.65f, 0.05f, 0.05f), green = v3(0.12f, 0.45f, 0.15f);
+  add_quad(g, cb_v(0, 0, 0), cb_v(555, 0, 0), cb_v(555, 0, 555), cb_v(0, 0, 555), white, st.floor_mat,
+           st.floor_extra, -1.0f);
+  add_quad(g, cb_v(0, 555, 0), cb_v(0, 555, 555), cb_v(555, 555, 555), cb_v(555, 555, 0), white, LAMBERTIAN, 0.0f,
+           -1.0f);
+  add_quad(g, cb_v(0, 0, 555), cb_v(555, 0, 555), cb_v(555, 555, 555), cb_v(0, 555, 555), white, LAMBERTIAN, 0.0f,
+           -1.0f);
+  add_quad(g, cb_v(0, 0, 0), cb_v(0, 555, 0), cb_v(0, 555, 555), cb_v(0, 0, 555), green, LAMBERTIAN, 0.0f, -1.0f);
+  add_quad(g, cb_v(555, 0, 0), cb_v(555, 0, 555), cb_v(555, 555, 555), cb_v(555, 555, 0), red, LAMBERTIAN, 0.0f,
+           -1.0f);
+  add_quad(g, cb_v(st.lx0, 554, st.lz0), cb_v(st.lx1, 554, st.lz0), cb_v(st.lx1, 554, st.lz1),
+           cb_v(st.lx0, 554, st.lz1), st.light_color, LIGHT, 0.0f, -1.0f);
+}
+
+SceneData one_geometry_scene(Geometry&& g, const CameraConfig& cam) {
+  SceneData sd;
+  sd.camera = cam;
+  sd.geometries.push_back(std::move(g));
+  sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  return sd;
+}
+
+// procedural.rs:16-171 (the OBJ variant is unreachable from factory.rs:12 — `cornell` passes None)
+SceneData scene_cornell() {
+  Geometry g;
+  V3 white = v3(0.73f, 0.73f, 0.73f);
+  add_cornell_shell(g, CornellStyle{LAMBERTIAN, 0.0f, v3(20, 20, 20), 213, 227, 343, 332});
+  add_box(g, cb_sz(165, 330, 165), cb_v(297.5f, 165, 378.5f), -15.0f, white, LAMBERTIAN, 0.0f, -1.0f);
+  add_box(g, cb_sz(165, 165, 165), cb_v(232.5f, 82.5f, 147.5f), 18.0f, white, LAMBERTIAN, 0.0f, -1.0f);
+  CameraConfig cam{v3(0, 1, -2.4f), v3(0, 1, 0), v3(0, 1, 0), 60.0f, 0.0f, 2.4f};
+  return one_geometry_scene(std::move(g), cam);
+}
+
+// procedural.rs:266-376
+SceneData scene_mixed() {
+  Geometry g;
+  const float PI = 3.14159274101257324219f;
+  add_box(g, v3(40, 2, 40), v3(0, -1.0f, 0), 0.0f, v3(0.1f, 0.1f, 0.1f), METAL, 0.05f, -1.0f);
+  V3 la = v3(-4, 8, 4);
+  add_quad(g, la, la + v3(2, 0, 0), la + v3(2, 0, 2), la + v3(0, 0, 2), v3(40, 30, 10), LIGHT, 0.0f, -1.0f);
+  V3 lb = v3(4, 6, -4);
+  add_quad(g, lb, lb + v3(3, 0, 0), lb + v3(3, -3, 0), lb + v3(0, -3, 0), v3(5, 10, 20), LIGHT, 0.0f, -1.0f);
+  add_box(g, v3(2, 1, 2), v3(0, 0.5f, 0), 0.0f, v3(0.8f, 0.6f, 0.2f), METAL, 0.1f, -1.0f);
+  add_sphere(g, v3(0, 1.8f, 0), 0.8f, v3(1, 1, 1), DIELECTRIC, 1.5f, -1.0f);
+  add_sphere(g, v3(0, 1.8f, 0), -0.7f, v3(1, 1, 1), DIELECTRIC, 1.0f, -1.0f);
+  add_box(g, v3(0.8f, 0.8f, 0.8f), v3(0, 3.2f, 0), 15.0f, v3(0.9f, 0.1f, 0.1f), METAL, 0.2f, -1.0f);
+  for (int i = 0; i < 12; i++) {
+    float fi = (float)i;
+    float angle = fi / 12.0f * PI * 2.0f;
+    V3 pos = v3(std::cos(angle) * 4.0f, 1.0f + std::sin(angle * 3.0f) * 0.5f, std::sin(angle) * 4.0f);
+    if (i % 2 == 0) {
+      add_sphere(g, pos, 0.4f, v3(0.8f, 0.8f, 0.8f), METAL, 0.0f, -1.0f);
+    } else {
+      V3 col = v3(0.5f + 0.5f * std::cos(fi), 0.5f + 0.5f * std::sin(fi), 0.8f);
+      add_box(g, v3(0.6f, 0.6f, 0.6f), pos, fi * 20.0f, col, LAMBERTIAN, 0.0f, -1.0f);
+    }
+  }
+  add_box(g, v3(1, 6, 1), v3(-4, 3, -6), 10.0f, v3(0.2f, 0.2f, 0.3f), LAMBERTIAN, 0.0f, -1.0f);
+  add_box(g, v3(1, 4, 1), v3(4, 2, -5), -20.0f, v3(0.2f, 0.2f, 0.3f), LAMBERTIAN, 0.0f, -1.0f);
+  CameraConfig cam{v3(0, 3.5f, 9), v3(0, 1.5f, 0), v3(0, 1, 0), 40.0f, 0.3f, 9.0f};
+  return one_geometry_scene(std::move(g), cam);
+}
+
+// procedural.rs:378-508
+SceneData scene_special() {
+  Geometry g;
+  V3 white = v3(0.73f, 0.73f, 0.73f);
+  add_cornell_shell(g, CornellStyle{METAL, 0.1f, v3(10, 10, 10), 213, 227, 343, 332});
+  V3 tall = cb_v(366, 165, 383);
+  add_box(g, cb_sz(165, 330, 165), tall, 15.0f, v3(0.95f, 0.95f, 0.95f), DIELECTRIC, 1.5f, -1.0f);
+  add_box(g, cb_sz(165, 165, 165), cb_v(183, 82.5f, 209), -18.0f, white, METAL, 0.2f, -1.0f);
+  add_sphere(g, tall, (60.0f / 555.0f) * 1.0f, v3(0.1f, 0.1f, 10.0f), LIGHT, 0.0f, -1.0f);
+  CameraConfig cam{v3(0, 1, -3.9f), v3(0, 1, 0), v3(0, 1, 0), 40.0f, 0.0f, 2.4f};
+  return one_geometry_scene(std::move(g), cam);
+}
+
+// procedural.rs:510-595
+SceneData scene_mesh() {
+  static const char* kCube =
+      "v -1 -1 1\nv 1 -1 1\nv -1 1 1\nv 1 1 1\nv -1 -1 -1\nv 1 -1 -1\nv -1 1 -1\nv 1 1 -1\n"
+      "f 1 2 4 3\nf 3 4 8 7\nf 7 8 6 5\nf 5 6 2 1\nf 3 7 5 1\nf 8 4 2 6";
+  Geometry g;
+  ObjMesh cube = parse_obj(kCube);
+  add_sphere(g, v3(0, -1000, 0), 1000.0f, v3(0.5f, 0.5f, 0.5f), LAMBERTIAN, 0.0f, -1.0f);
+  add_mesh_instance(g, cube, v3(-2, 1, 0), 1.0f, 45.0f, v3(0.8f, 0.2f, 0.2f), METAL, 0.2f, -1.0f);
+  add_mesh_instance(g, cube, v3(0, 1, 1.5f), 1.2f, 0.0f, v3(1, 1, 1), DIELECTRIC, 1.5f, -1.0f);
+  for (int i = 0; i < 5; i++) {
+    float fi = (float)i;
+    add_mesh_instance(g, cube, v3(2.0f + fi * 0.5f, 0.5f + fi * 0.5f, -fi), 0.5f, fi * 30.0f, v3(0.2f, 0.4f, 0.8f),
+                      LAMBERTIAN, 0.0f, -1.0f);
+  }
+  add_sphere(g, v3(0, 10, 0), 3.0f, v3(10, 10, 10), LIGHT, 0.0f, -1.0f);
+  CameraConfig cam{v3(0, 3, 6), v3(0, 1, 0), v3(0, 1, 0), 40.0f, 0.0f, 6.0f};
+  return one_geometry_scene(std::move(g), cam);
+}
+
+// procedural.rs:634-791
+SceneData scene_viewer(const ObjMesh* mesh) {
+  Geometry env, model;
+  add_cornell_shell(env, CornellStyle{METAL, 0.15f, v3(10, 10, 10), 150, 150, 405, 405});
+  if (mesh) {
+    add_mesh_instance(model, *mesh, v3(0, 1, 0), 1.0f, 0.0f, v3(0.8f, 0.8f, 0.8f), LAMBERTIAN, 0.0f, -1.0f);
+  } else {
+    add_sphere(model, v3(0, 1, 0), 0.5f, v3(1, 0, 1), LAMBERTIAN, 0.0f, -1.0f);  // placeholder
+  }
+  SceneData sd;
+  sd.camera = CameraConfig{v3(0, 1, -3.9f), v3(0, 1, 0), v3(0, 1, 0), 40.0f, 0.0f, 3.9f};
+  bool has_model = !model.positions.empty();
+  sd.geometries.push_back(std::move(env));
+  sd.geometries.push_back(std::move(model));
+  sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  if (has_model) sd.instances.push_back(SceneInstance{m4_identity(), 1});
+  return sd;
+}
+
+// ---- extensions: BASELINE.json configs 3-5 (not expressible by World::update) ----
+ObjMesh octahedron_mesh() {  // same shape as public/diamond.obj (6 vertices, 8 faces, no vn/vt)
+  return parse_obj(
+      "v 0 1 0\nv 1 0 0\nv 0 0 1\nv -1 0 0\nv 0 0 -1\nv 0 -1 0\n"
+      "f 1 3 2\nf 1 2 5\nf 1 5 4\nf 1 4 3\nf 6 2 3\nf 6 5 2\nf 6 4 5\nf 6 3 4\n");
+}
+
+// Config 3: Cornell shell (instance 0) + 10x10x10 lattice of octahedra sharing
+// three BLASes (Lambert / metal 0.2 / dielectric 1.5), scale 0.06, rotY(0.37 i).
+SceneData scene_instanced1000() {
+  SceneData sd;
+  Geometry env;
+  add_cornell_shell(env, CornellStyle{LAMBERTIAN, 0.0f, v3(20, 20, 20), 213, 227, 343, 332});
+  sd.geometries.push_back(std::move(env));
+  ObjMesh oct = octahedron_mesh();
+  const V3 colors[3] = {v3(0.8f, 0.3f, 0.3f), v3(0.9f, 0.9f, 0.9f), v3(1.0f, 1.0f, 1.0f)};
+  const uint32_t mats[3] = {LAMBERTIAN, METAL, DIELECTRIC};
+  const float extras[3] = {0.0f, 0.2f, 1.5f};
+  for (int k = 0; k < 3; k++) {
+    Geometry g;
+    add_mesh_instance(g, oct, v3(0, 0, 0), 1.0f, 0.0f, colors[k], mats[k], extras[k], -1.0f);
+    sd.geometries.push_back(std::move(g));
+  }
+  sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  int i = 0;
+  for (int iz = 0; iz < 10; iz++)
+    for (int iy = 0; iy < 10; iy++)
+      for (int ix = 0; ix < 10; ix++, i++) {
+        V3 p = v3(-0.81f + 0.18f * (float)ix, 0.19f + 0.18f * (float)iy, -0.81f + 0.18f * (float)iz);
+        M4 t = m4_mul(m4_from_translation(p),
+                      m4_mul(m4_from_rotation_y(0.37f * (float)i), m4_from_scale(v3(0.06f, 0.06f, 0.06f))));
+        sd.instances.push_back(SceneInstance{t, (size_t)(1 + i % 3)});
+      }
+  sd.camera = CameraConfig{v3(0, 1, -2.4f), v3(0, 1, 0), v3(0, 1, 0), 60.0f, 0.0f, 2.4f};
+  sd.keep_instance_transforms = true;
+  return sd;
+}
+
+// Deterministic LCG for procedural texture / geometry noise (scene generation only).
+struct Lcg {
+  uint32_t s;
+  explicit Lcg(uint32_t seed) : s(seed) {}
+  uint32_t next() {
+    s = s * 1664525u + 1013904223u;
+    return s;
+  }
+  float unit() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+};
+
+void make_texture(std::vector<uint8_t>& out, int kind, uint32_t seed) {
+  const int N = RT_TEX_SIZE;
+  out.resize((size_t)N * N * 4);
+  Lcg rng(seed);
+  std::vector<uint8_t> noise((size_t)64 * 64);
+  for (auto& v : noise) v = (uint8_t)(rng.next() >> 24);
+  for (int y = 0; y < N; y++)
+    for (int x = 0; x < N; x++) {
+      uint8_t* px = &out[((size_t)y * N + x) * 4];
+      int n = noise[(size_t)((y >> 4) & 63) * 64 + ((x >> 4) & 63)];
+      int r, g, b;
+      switch (kind & 3) {
+        case 0: {  // checker
+          int c = (((x >> 6) + (y >> 6)) & 1) ? 220 : 90;
+          r = c; g = c - 10; b = c - 30;
+        } break;
+        case 1: {  // brick
+          int row = y >> 5;
+          int xx = x + ((row & 1) ? 32 : 0);
+          bool mortar = ((y & 31) < 3) || ((xx & 63) < 3);
+          r = mortar ? 200 : 150 + (n >> 3); g = mortar ? 200 : 70 + (n >> 4); b = mortar ? 190 : 50;
+        } break;
+        case 2: {  // blocky noise
+          r = 100 + (n >> 1); g = 110 + (n >> 2); b = 120 + (n >> 3);
+        } break;
+        default: {  // metal-roughness map: g = roughness scale, b = metallic scale
+          r = 255; g = 40 + (n >> 1); b = (((x >> 7) + (y >> 7)) & 1) ? 255 : 60;
+        } break;
+      }
+      px[0] = (uint8_t)std::min(255, std::max(0, r));
+      px[1] = (uint8_t)std::min(255, std::max(0, g));
+      px[2] = (uint8_t)std::min(255, std::max(0, b));
+      px[3] = 255;
+    }
+}
+
+// Tessellated helpers for the large synthetic scenes: smooth normals, real UVs.
+void add_grid_patch(Geometry& g, int nu, int nv, V3 (*fn)(float, float, const float*), const float* prm, V3 color,
+                    uint32_t mat, float metallic, float roughness, float ior, const float tex[4], float uv_scale) {
+  uint32_t start = (uint32_t)g.positions.size();
+  const float eps = 1e-3f;
+  for (int j = 0; j <= nv; j++)
+    for (int i = 0; i <= nu; i++) {
+      float u = (float)i / (float)nu, v = (float)j / (float)nv;
+      V3 p = fn(u, v, prm);
+      V3 du = fn(u + eps, v, prm) - fn(u - eps, v, prm);
+      V3 dv = fn(u, v + eps, prm) - fn(u, v - eps, prm);
+      V3 n = normalize_or_zero(cross(du, dv));
+      if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) n = v3(0, 1, 0);
+      g.push_vertex(p, n, V2{u * uv_scale, v * uv_scale});
+    }
+  for (int j = 0; j < nv; j++)
+    for (int i = 0; i < nu; i++) {
+      uint32_t a = start + (uint32_t)(j * (nu + 1) + i), b = a + 1, c = a + (uint32_t)(nu + 1), d = c + 1;
+      const uint32_t t0[3] = {a, b, d}, t1[3] = {a, d, c};
+      g.indices.insert(g.indices.end(), t0, t0 + 3);
+      g.push_attributes(color, mat, metallic, roughness, ior, v3(0, 0, 0), tex, -1.0f);
+      g.indices.insert(g.indices.end(), t1, t1 + 3);
+      g.push_attributes(color, mat, metallic, roughness, ior, v3(0, 0, 0), tex, -1.0f);
+    }
+}
+V3 fn_cylinder(float u, float v, const float* p) {  // p: cx, cz, radius, y0, y1
+  float a = 6.28318548202514648438f * u;
+  return v3(p[0] + p[2] * std::cos(a), p[3] + (p[4] - p[3]) * v, p[1] + p[2] * std::sin(a));
+}
+V3 fn_arch(float u, float v, const float* p) {  // half-torus arch: cx0, cx1, z, y, tube radius
+  float a = 3.14159274101257324219f * u, b = 6.28318548202514648438f * v;
+  float R = (p[1] - p[0]) * 0.5f, cx = (p[0] + p[1]) * 0.5f;
+  float rr = R + p[4] * std::cos(b);
+  return v3(cx - rr * std::cos(a), p[3] + rr * std::sin(a), p[2] + p[4] * std::sin(b));
+}
+V3 fn_plane_xz(float u, float v, const float* p) {  // x0,x1,z0,z1,y, flip
+  float x = p[0] + (p[1] - p[0]) * (p[5] > 0 ? v : u), z = p[2] + (p[3] - p[2]) * (p[5] > 0 ? u : v);
+  return v3(x, p[4], z);
+}
+V3 fn_plane_xy(float u, float v, const float* p) {  // x0,x1,y0,y1,z, flip
+  float x = p[0] + (p[1] - p[0]) * (p[5] > 0 ? v : u), y = p[2] + (p[3] - p[2]) * (p[5] > 0 ? u : v);
+  return v3(x, y, p[4]);
+}
+V3 fn_plane_zy(float u, float v, const float* p) {  // z0,z1,y0,y1,x, flip
+  float z = p[0] + (p[1] - p[0]) * (p[5] > 0 ? v : u), y = p[2] + (p[3] - p[2]) * (p[5] > 0 ? u : v);
+  return v3(p[4], y, z);
+}
+V3 fn_torus_knot(float u, float v, const float* p) {  // (2,3) torus knot tube: scale, tube r, cy
+  const float TWO_PI = 6.28318548202514648438f;
+  auto center = [&](float t) {
+    float r = 0.5f * (2.0f + std::cos(3.0f * t));
+    return v3(r * std::cos(2.0f * t), r * std::sin(3.0f * t) * 0.9f, r * std::sin(2.0f * t)) * p[0];
+  };
+  float t = TWO_PI * u, a = TWO_PI * v;
+  V3 c = center(t);
+  V3 tan = normalize(center(t + 0.01f) - center(t - 0.01f));
+  V3 up = v3(0, 1, 0);
+  V3 nrm = normalize(cross(tan, up));
+  V3 bin = cross(tan, nrm);
+  V3 q = c + nrm * (p[1] * std::cos(a)) + bin * (p[1] * std::sin(a));
+  return v3(q.x, q.y + p[2], q.z);
+}
+
+// Config 4: "Sponza-like" hall, ~262k triangles, 8 procedural textures,
+// Lambert + textured metal, 4 ceiling light quads.
+SceneData scene_sponza_like() {
+  SceneData sd;
+  Geometry g;
+  sd.textures_rgba.resize(8);
+  for (int i = 0; i < 8; i++) make_texture(sd.textures_rgba[i], i, 1u + (uint32_t)i);
+  const float t_floor[4] = {0, -1, -1, -1}, t_wall[4] = {1, -1, -1, -1}, t_col[4] = {2, 3, -1, -1},
+              t_arch[4] = {5, -1, -1, -1}, t_ceil[4] = {6, -1, -1, -1}, t_metal[4] = {4, 7, -1, -1};
+  // hall: x in [-6,6], y in [0,5], z in [-2.5,2.5]
+  {
+    const float fl[6] = {-6, 6, -2.5f, 2.5f, 0, 1};
+    add_grid_patch(g, 128, 128, fn_plane_xz, fl, v3(0.8f, 0.8f, 0.8f), METAL, 0.6f, 0.35f, 1.5f, t_metal, 6.0f);
+    const float ce[6] = {-6, 6, -2.5f, 2.5f, 5, 0};
+    add_grid_patch(g, 96, 96, fn_plane_xz, ce, v3(0.7f, 0.7f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_ceil, 4.0f);
+    const float bk[6] = {-6, 6, 0, 5, 2.5f, 1};
+    add_grid_patch(g, 128, 64, fn_plane_xy, bk, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f);
+    const float fr[6] = {-6, 6, 0, 5, -2.5f, 0};
+    add_grid_patch(g, 128, 64, fn_plane_xy, fr, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f);
+    const float lf[6] = {-2.5f, 2.5f, 0, 5, -6, 0};
+    add_grid_patch(g, 64, 64, fn_plane_zy, lf, v3(0.65f, 0.3f, 0.25f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f);
+    const float rt[6] = {-2.5f, 2.5f, 0, 5, 6, 1};
+    add_grid_patch(g, 64, 64, fn_plane_zy, rt, v3(0.3f, 0.45f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f);
+  }
+  // two colonnades of 8 columns + arches between neighbours
+  for (int side = 0; side < 2; side++) {
+    float z = side == 0 ? -1.4f : 1.4f;
+    for (int k = 0; k < 8; k++) {
+      float x = -5.25f + 1.5f * (float)k;
+      const float cy[5] = {x, z, 0.18f, 0.0f, 3.0f};
+      add_grid_patch(g, 64, 48, fn_cylinder, cy, v3(0.85f, 0.8f, 0.7f), METAL, 1.0f, 0.5f, 1.5f, t_col, 2.0f);
+      if (k < 7) {
+        const float ar[5] = {x, x + 1.5f, z, 3.0f, 0.14f};
+        add_grid_patch(g, 64, 36, fn_arch, ar, v3(0.8f, 0.75f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_arch, 2.0f);
+      }
+    }
+  }
+  // four ceiling lights
+  for (int k = 0; k < 4; k++) {
+    float x = -4.5f + 3.0f * (float)k;
+    add_quad(g, v3(x - 0.5f, 4.98f, -0.5f), v3(x + 0.5f, 4.98f, -0.5f), v3(x + 0.5f, 4.98f, 0.5f),
+             v3(x - 0.5f, 4.98f, 0.5f), v3(18, 17, 15), LIGHT, 0.0f, -1.0f);
+  }
+  sd.geometries.push_back(std::move(g));
+  sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  sd.camera = CameraConfig{v3(-5.2f, 1.7f, 0.0f), v3(0, 1.9f, 0.0f), v3(0, 1, 0), 65.0f, 0.0f, 5.0f};
+  sd.keep_instance_transforms = true;
+  return sd;
+}
+
+// Config 5: Cornell box + ~200k-triangle dielectric (ior 1.5) torus knot.
+SceneData scene_glass_blob() {
+  SceneData sd;
+  Geometry env;
+  add_cornell_shell(env, CornellStyle{LAMBERTIAN, 0.0f, v3(20, 20, 20), 213, 227, 343, 332});
+  Geometry blob;
+  const float prm[3] = {0.42f, 0.12f, 0.95f};
+  const float notex[4] = {-1, -1, -1, -1};
+  add_grid_patch(blob, 1600, 64, fn_torus_knot, prm, v3(0.98f, 0.98f, 0.98f), DIELECTRIC, 0.0f, 0.0f, 1.5f, notex,
+                 1.0f);
+  sd.geometries.push_back(std::move(env));
+  sd.geometries.push_back(std::move(blob));
+  sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  sd.instances.push_back(SceneInstance{m4_identity(), 1});
+  sd.camera = CameraConfig{v3(0, 1, -2.4f), v3(0, 1, 0), v3(0, 1, 0), 60.0f, 0.0f, 2.4f};
+  sd.keep_instance_transforms = true;
+  return sd;
+}
+
+// ------------------------------------------------------------------ BLAS
+// Binned-SAH builder: 16 bins, leaf <= 4, DFS pre-order + skip pointers (bvh/blas.rs).
+struct BuildNode {
+  V3 mn, mx;
+  uint32_t skip = 0, data = 0;
+};
+class BlasBuilder {
+ public:
+  BlasBuilder(const std::vector<float>& verts4, const std::vector<uint32_t>& indices) : indices_(indices) {
+    size_t n = indices.size() / 3;
+    boxes_.reserve(n);
+    centers_.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+      auto get = [&](uint32_t id) { return v3(verts4[id * 4], verts4[id * 4 + 1], verts4[id * 4 + 2]); };
+      V3 a = get(indices[i * 3]), b = get(indices[i * 3 + 1]), c = get(indices[i * 3 + 2]);
+      V3 mn = vmin(vmin(a, b), c), mx = vmax(vmax(a, b), c);
+      V3 size = mx - mn;
+      const float eps = 1e-5f;
+      V3 pad = v3(size.x < eps ? eps : 0.0f, size.y < eps ? eps : 0.0f, size.z < eps ? eps : 0.0f);
+      Aabb bx{mn - pad * 0.5f, mx + pad * 0.5f};
+      boxes_.push_back(bx);
+      centers_.push_back(aabb_center(bx));
+    }
+  }
+  void build() {
+    nodes.clear();
+    order.resize(indices_.size() / 3);
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    if (!order.empty()) subdivide(0, order.size());
+  }
+  std::vector<BuildNode> nodes;
+  std::vector<size_t> order;  // sorted position -> original triangle id
+
+ private:
+  void make_leaf(size_t node, size_t first, size_t count) {
+    // NOTE: count > 7 overflows the 3-bit field exactly like the reference (blas.rs:111-115)
+    nodes[node].data = ((uint32_t)first << 3) | (uint32_t)count;
+    nodes[node].skip = (uint32_t)nodes.size();
+  }
+  void subdivide(size_t first, size_t count) {
+    size_t node = nodes.size();
+    nodes.emplace_back();
+    Aabb bb;
+    for (size_t i = 0; i < count; i++) bb = aabb_union(bb, boxes_[order[first + i]]);
+    nodes[node].mn = bb.mn;
+    nodes[node].mx = bb.mx;
+    if (count <= 4) return make_leaf(node, first, count);
+
+    V3 ext = bb.mx - bb.mn;
+    int axis = ext.y > ext.x ? 1 : ((ext.z > ext.x && ext.z > ext.y) ? 2 : 0);
+    float split_len = ext[axis], split_min = bb.mn[axis];
+    if (split_len < 1e-6f) return make_leaf(node, first, count);
+
+    const int BINS = 16;
+    float scale = (float)BINS / split_len;
+    auto bin_of = [&](float val) -> size_t {
+      float f = (val - split_min) * scale;
+      size_t idx = (f != f || f <= 0.0f) ? 0 : (f >= 1.8446744e19f ? (size_t)-1 : (size_t)f);  // `as usize`
+      return idx < (size_t)(BINS - 1) ? idx : (size_t)(BINS - 1);
+    };
+    Aabb bin_box[BINS];
+    uint32_t bin_cnt[BINS] = {0};
+    for (size_t i = 0; i < count; i++) {
+      size_t t = order[first + i];
+      size_t b = bin_of(centers_[t][axis]);
+      bin_cnt[b]++;
+      bin_box[b] = aabb_union(bin_box[b], boxes_[t]);
+    }
+    float l_area[BINS], r_area[BINS];
+    uint32_t l_cnt[BINS], r_cnt[BINS];
+    {
+      Aabb cur;
+      uint32_t sum = 0;
+      for (int i = 0; i < BINS; i++) {
+        sum += bin_cnt[i];
+        cur = aabb_union(cur, bin_box[i]);
+        l_area[i] = aabb_area(cur);
+        l_cnt[i] = sum;
+      }
+      cur = Aabb();
+      sum = 0;
+      for (int i = BINS - 1; i >= 0; i--) {
+        sum += bin_cnt[i];
+        cur = aabb_union(cur, bin_box[i]);
+        r_area[i] = aabb_area(cur);
+        r_cnt[i] = sum;
+      }
+    }
+    float best = INFINITY;
+    int best_split = -1;
+    for (int i = 0; i < BINS - 1; i++) {
+      if (l_cnt[i] == 0 || r_cnt[i + 1] == 0) continue;
+      float cost = l_area[i] * (float)l_cnt[i] + r_area[i + 1] * (float)r_cnt[i + 1];
+      if (cost < best) {
+        best = cost;
+        best_split = i;
+      }
+    }
+    if (best_split < 0) return make_leaf(node, first, count);
+
+    // two-pointer partition (blas.rs:179-199)
+    size_t i = first, j = first + count - 1;
+    while (i <= j) {
+      if (bin_of(centers_[order[i]][axis]) <= (size_t)best_split) {
+        i++;
+      } else if (bin_of(centers_[order[j]][axis]) > (size_t)best_split) {
+        if (j == 0) break;
+        j--;
+      } else {
+        std::swap(order[i], order[j]);
+        i++;
+        if (j == 0) break;
+        j--;
+      }
+    }
+    size_t l_count = i - first, r_count = count - l_count;
+    if (l_count == 0 || l_count == count) return make_leaf(node, first, count);
+
+    // static front-to-back heuristic: the costlier child goes first (blas.rs:209-217)
+    float l_cost = l_area[best_split] * (float)l_count;
+    float r_cost = r_area[best_split + 1] * (float)r_count;
+    if (r_cost > l_cost) {
+      std::rotate(order.begin() + first, order.begin() + first + l_count, order.begin() + first + count);
+      std::swap(l_count, r_count);
+    }
+    nodes[node].data = 0;
+    subdivide(first, l_count);
+    subdivide(first + l_count, r_count);
+    nodes[node].skip = (uint32_t)nodes.size();
+  }
+  const std::vector<uint32_t>& indices_;
+  std::vector<Aabb> boxes_;
+  std::vector<V3> centers_;
+};
+
+void pack_nodes(const std::vector<BuildNode>& nodes, std::vector<float>& out) {
+  for (const BuildNode& n : nodes) {
+    float f[8];
+    f[0] = n.mn.x; f[1] = n.mn.y; f[2] = n.mn.z;
+    std::memcpy(&f[3], &n.skip, 4);
+    f[4] = n.mx.x; f[5] = n.mx.y; f[6] = n.mx.z;
+    std::memcpy(&f[7], &n.data, 4);
+    out.insert(out.end(), f, f + 8);
+  }
+}
+
+// ------------------------------------------------------------------ TLAS
+// Median split on sorted centres, leaf = one instance (bvh/tlas.rs).
+struct RawInstance {
+  M4 transform, inverse;
+  uint32_t blas_node_offset = 0, attr_offset = 0, instance_id = 0, pad = 0;
+};
+class TlasBuilder {
+ public:
+  TlasBuilder(const std::vector<RawInstance>& inst, const std::vector<Aabb>& blas_boxes) : inst_(inst) {
+    for (size_t i = 0; i < inst.size(); i++) {
+      Aabb wb = aabb_transform(blas_boxes[i], inst[i].transform);
+      boxes_.push_back(wb);
+      centers_.push_back(aabb_center(wb));
+      order.push_back(i);
+    }
+  }
+  void build() {
+    nodes.clear();
+    if (!inst_.empty()) subdivide(0, inst_.size());
+  }
+  std::vector<BuildNode> nodes;
+  std::vector<size_t> order;
+
+ private:
+  void subdivide(size_t first, size_t count) {
+    size_t node = nodes.size();
+    nodes.emplace_back();
+    Aabb bb;
+    for (size_t i = 0; i < count; i++) bb = aabb_union(bb, boxes_[order[first + i]]);
+    nodes[node].mn = bb.mn;
+    nodes[node].mx = bb.mx;
+    if (count == 1) {
+      nodes[node].data = ((uint32_t)first << 3) | 1u;
+      nodes[node].skip = (uint32_t)nodes.size();
+      return;
+    }
+    V3 ext = bb.mx - bb.mn;
+    int axis = ext.y > ext.x ? 1 : ((ext.z > ext.x && ext.z > ext.y) ? 2 : 0);
+    std::stable_sort(order.begin() + first, order.begin() + first + count,
+                     [&](size_t a, size_t b) { return centers_[a][axis] < centers_[b][axis]; });
+    size_t mid = count / 2, l_count = mid, r_count = count - mid;
+    Aabb lb, rb;
+    for (size_t i = 0; i < l_count; i++) lb = aabb_union(lb, boxes_[order[first + i]]);
+    for (size_t i = 0; i < r_count; i++) rb = aabb_union(rb, boxes_[order[first + mid + i]]);
+    if (aabb_area(rb) * (float)r_count > aabb_area(lb) * (float)l_count) {
+      std::rotate(order.begin() + first, order.begin() + first + l_count, order.begin() + first + count);
+      std::swap(l_count, r_count);
+    }
+    nodes[node].data = 0;
+    subdivide(first, l_count);
+    subdivide(first + l_count, r_count);
+    nodes[node].skip = (uint32_t)nodes.size();
+  }
+  const std::vector<RawInstance>& inst_;
+  std::vector<Aabb> boxes_;
+  std::vector<V3> centers_;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ World
+struct ms_world {
+  SceneData scene;
+  std::vector<RawInstance> raw_instances;
+  std::vector<Aabb> instance_blas_boxes;
+  std::vector<uint32_t> blas_root_offsets;
+  // bridge arrays (render_buffers.rs:6-17)
+  std::vector<float> vertices, normals, uvs, tlas, blas, instances, camera;
+  std::vector<uint32_t> topology, lights, draw_commands;
+};
+
+static thread_local std::string g_last_error;
+
+static void world_update(ms_world& w) {
+  // --- rebuilder.rs:9-190: per geometry, vertices + BLAS + topology ---
+  w.vertices.clear();
+  w.normals.clear();
+  w.uvs.clear();
+  w.topology.clear();
+  w.blas.clear();
+  w.lights.clear();
+  w.draw_commands.clear();
+  w.blas_root_offsets.clear();
+  std::vector<std::vector<uint32_t>> emissive(w.scene.geometries.size());
+  std::vector<std::pair<uint32_t, uint32_t>> geom_ranges(w.scene.geometries.size(), {0u, 0u});
+  uint32_t node_offset = 0;
+  for (size_t gi = 0; gi < w.scene.geometries.size(); gi++) {
+    const Geometry& geo = w.scene.geometries[gi];
+    if (geo.positions.empty()) {
+      w.blas_root_offsets.push_back(0);
+      continue;
+    }
+    std::vector<float> v4, n4, uv2;
+    v4.reserve(geo.positions.size() * 4);
+    for (size_t i = 0; i < geo.positions.size(); i++) {
+      V3 p = geo.positions[i], n = geo.normals[i];
+      V2 uv = i < geo.uvs.size() ? geo.uvs[i] : V2{0, 0};
+      if (is_nan(p)) p = v3(0, 0, 0);
+      if (is_nan(n)) n = v3(0, 0, 1);
+      const float pv[4] = {p.x, p.y, p.z, 1.0f}, nv[4] = {n.x, n.y, n.z, 0.0f};
+      v4.insert(v4.end(), pv, pv + 4);
+      n4.insert(n4.end(), nv, nv + 4);
+      uv2.push_back(uv.x);
+      uv2.push_back(uv.y);
+    }
+    BlasBuilder bb(v4, geo.indices);
+    bb.build();
+    uint32_t v_offset = (uint32_t)(w.vertices.size() / 4);
+    uint32_t topo_start = (uint32_t)(w.topology.size() / 20);
+    for (BuildNode& n : bb.nodes)
+      if (n.data != 0) n.data = (((n.data >> 3) + topo_start) << 3) | (n.data & 7u);
+    for (size_t i = 0; i < bb.order.size(); i++) {
+      size_t old_id = bb.order[i];
+      uint32_t row[20];
+      row[0] = geo.indices[old_id * 3] + v_offset;
+      row[1] = geo.indices[old_id * 3 + 1] + v_offset;
+      row[2] = geo.indices[old_id * 3 + 2] + v_offset;
+      row[3] = (uint32_t)gi;
+      std::memcpy(&row[4], &geo.attributes[old_id * 16], 64);
+      w.topology.insert(w.topology.end(), row, row + 20);
+      float mat_val = geo.attributes[old_id * 16 + 3];
+      if (std::fabs(mat_val - 3.0f) < 1e-6f) emissive[gi].push_back(topo_start + (uint32_t)i);
+    }
+    w.vertices.insert(w.vertices.end(), v4.begin(), v4.end());
+    w.normals.insert(w.normals.end(), n4.begin(), n4.end());
+    w.uvs.insert(w.uvs.end(), uv2.begin(), uv2.end());
+    pack_nodes(bb.nodes, w.blas);
+    w.blas_root_offsets.push_back(node_offset);
+    node_offset += (uint32_t)bb.nodes.size();
+    geom_ranges[gi] = {topo_start, (uint32_t)(w.topology.size() / 20) - topo_start};
+  }
+
+  // --- lib.rs:194-230: instance transforms, BLAS offsets, local boxes ---
+  for (size_t i = 0; i < w.raw_instances.size(); i++) {
+    RawInstance& inst = w.raw_instances[i];
+    if (i > 0 && !w.scene.keep_instance_transforms) {
+      // quirk kept: every instance after the first is overwritten with rotY(pi) * scale(0.7)
+      M4 t = m4_mul(m4_from_rotation_y(3.14159274101257324219f), m4_from_scale(v3(0.7f, 0.7f, 0.7f)));
+      inst.transform = t;
+      inst.inverse = m4_inverse(t);
+    }
+    size_t gi = inst.instance_id;
+    if (gi < w.blas_root_offsets.size()) {
+      inst.blas_node_offset = w.blas_root_offsets[gi];
+      size_t base = (size_t)inst.blas_node_offset * 8;
+      if (base < w.blas.size())
+        w.instance_blas_boxes[i] = Aabb{v3(w.blas[base], w.blas[base + 1], w.blas[base + 2]),
+                                        v3(w.blas[base + 4], w.blas[base + 5], w.blas[base + 6])};
+    }
+  }
+
+  // --- lib.rs:232-270: TLAS, lights, draw commands, instance packing ---
+  TlasBuilder tb(w.raw_instances, w.instance_blas_boxes);
+  tb.build();
+  w.tlas.clear();
+  pack_nodes(tb.nodes, w.tlas);
+  w.instances.clear();
+  for (size_t i = 0; i < tb.order.size(); i++) {
+    const RawInstance& inst = w.raw_instances[tb.order[i]];
+    size_t gi = inst.instance_id;
+    uint32_t v_count = 0, v_start = 0;
+    if (gi < w.blas_root_offsets.size()) {
+      if (gi < geom_ranges.size()) {
+        v_count = geom_ranges[gi].second * 3;
+        v_start = geom_ranges[gi].first * 3;
+      }
+      if (gi < emissive.size())
+        for (uint32_t tri : emissive[gi]) {
+          w.lights.push_back((uint32_t)i);
+          w.lights.push_back(tri);
+        }
+    }
+    const uint32_t dc[4] = {v_count, 1u, v_start, (uint32_t)i};
+    w.draw_commands.insert(w.draw_commands.end(), dc, dc + 4);
+    rt_instance packed;
+    std::memcpy(packed.transform, inst.transform.c, 64);
+    std::memcpy(packed.inverse, inst.inverse.c, 64);
+    packed.blas_node_offset = inst.blas_node_offset;
+    packed.attr_offset = inst.attr_offset;
+    packed.instance_id = inst.instance_id;
+    packed.pad = inst.pad;
+    const float* pf = reinterpret_cast<const float*>(&packed);
+    w.instances.insert(w.instances.end(), pf, pf + 36);
+  }
+}
+
+extern "C" {
+
+const char* ms_last_error(void) { return g_last_error.c_str(); }
+
+ms_world* ms_world_create(const char* scene_name, const char* obj_source) {
+  std::string name = scene_name ? scene_name : "cornell";
+  ObjMesh mesh;
+  bool has_mesh = obj_source != nullptr;
+  if (has_mesh) mesh = parse_obj(obj_source);
+  ms_world* w = new ms_world();
+  if (name == "spheres") {
+    g_last_error = "scene 'spheres' is seeded from rand::rng() in the reference and has no reproducible output";
+    delete w;
+    return nullptr;
+  } else if (name == "mixed") {
+    w->scene = scene_mixed();
+  } else if (name == "special") {
+    w->scene = scene_special();
+  } else if (name == "mesh") {
+    w->scene = scene_mesh();
+  } else if (name == "viewer") {
+    w->scene = scene_viewer(has_mesh ? &mesh : nullptr);
+  } else if (name == "instanced1000") {
+    w->scene = scene_instanced1000();
+  } else if (name == "sponza_like") {
+    w->scene = scene_sponza_like();
+  } else if (name == "glass_blob") {
+    w->scene = scene_glass_blob();
+  } else {
+    w->scene = scene_cornell();
+  }
+  for (const SceneInstance& si : w->scene.instances) {
+    RawInstance ri;
+    ri.transform = si.transform;
+    ri.inverse = m4_inverse(si.transform);
+    ri.instance_id = (uint32_t)si.geometry_index;
+    w->raw_instances.push_back(ri);
+    w->instance_blas_boxes.push_back(Aabb());
+  }
+  if (w->raw_instances.empty()) {
+    RawInstance ri;
+    ri.transform = m4_identity();
+    ri.inverse = m4_identity();
+    w->raw_instances.push_back(ri);
+    w->instance_blas_boxes.push_back(Aabb());
+  }
+  w->camera.assign(24, 0.0f);
+  world_update(*w);
+  return w;
+}
+
+void ms_world_destroy(ms_world* w) { delete w; }
+
+void ms_world_update(ms_world* w, float /*time*/) {
+  if (w) world_update(*w);
+}
+
+void ms_world_update_camera(ms_world* w, float width, float height) {
+  if (!w || height == 0.0f) return;
+  w->camera.resize(24);
+  camera_buffer(w->scene.camera, width / height, w->camera.data());
+}
+
+#define MS_GETTER(NAME, TYPE, FIELD)                         \
+  const TYPE* ms_world_##NAME(const ms_world* w, size_t* len) { \
+    if (len) *len = w ? w->FIELD.size() : 0;                 \
+    return w ? w->FIELD.data() : nullptr;                    \
+  }
+MS_GETTER(vertices, float, vertices)
+MS_GETTER(normals, float, normals)
+MS_GETTER(uvs, float, uvs)
+MS_GETTER(mesh_topology, uint32_t, topology)
+MS_GETTER(tlas, float, tlas)
+MS_GETTER(blas, float, blas)
+MS_GETTER(instances, float, instances)
+MS_GETTER(lights, uint32_t, lights)
+MS_GETTER(draw_commands, uint32_t, draw_commands)
+MS_GETTER(camera, float, camera)
+
+size_t ms_world_texture_count(const ms_world* w) { return w ? w->scene.textures_rgba.size() : 0; }
+const uint8_t* ms_world_texture_rgba(const ms_world* w, size_t index) {
+  if (!w || index >= w->scene.textures_rgba.size()) return nullptr;
+  return w->scene.textures_rgba[index].data();
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""WebGPURenderer — host-side mirror of src/renderer/WebGPURenderer.ts over libmi355rt.so.
+
+Same method names, argument meaning and return values as the reference class
+(WebGPURenderer.ts:7-138).  Every call goes through the C ABI in include/mi355rt.h; there is no
+CPU fallback: if the HIP library is missing or no device is present the constructor raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+RT_OK, RT_REALLOCATED, RT_SKIPPED = 0, 1, 2
+_KINDS = {"topology": 0, "instance": 1, "lights": 2, "draw_commands": 3}
+COUNTER_NAMES = ("primary_rays", "extension_rays", "shadow_rays", "nodes_visited", "tris_tested", "shaded_hits")
+
+_lib = None
+
+
+class RendererError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libmi355rt.so and declare every symbol of include/mi355rt.h.
+    Loading does not touch the GPU; rt_create does."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.RT_LIB
+    if not os.path.exists(path):
+        raise RendererError(
+            "HIP renderer library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    L = ctypes.CDLL(path)
+    vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
+    sigs = {
+        "rt_create": (vp, [i32]), "rt_destroy": (None, [vp]), "rt_last_error": (ctypes.c_char_p, [vp]),
+        "rt_set_pipeline": (i32, [vp, u32, u32]), "rt_resize": (i32, [vp, u32, u32]),
+        "rt_reset_accum": (i32, [vp]), "rt_upload_textures": (i32, [vp, vp, u32]),
+        "rt_upload": (i32, [vp, i32, vp, ctypes.c_size_t]),
+        "rt_upload_geometry": (i32, [vp, vp, vp, vp, u32]),
+        "rt_upload_bvh": (i32, [vp, vp, u32, vp, u32]),
+        "rt_set_scene": (i32, [vp, vp, u32, u32]), "rt_recreate_bind_group": (i32, [vp]),
+        "rt_compute": (i32, [vp, u32]), "rt_present": (i32, [vp]),
+        "rt_capture": (i32, [vp, vp, ctypes.c_size_t]), "rt_sync": (i32, [vp]),
+        "rt_read_accum": (i32, [vp, vp, ctypes.c_size_t]), "rt_write_accum": (i32, [vp, vp, ctypes.c_size_t]),
+        "rt_read_gbuffer": (i32, [vp, vp, vp, vp]), "rt_read_history": (i32, [vp, vp, ctypes.c_size_t]),
+        "rt_read_uniforms": (i32, [vp, vp]), "rt_get_counters": (i32, [vp, vp]),
+        "rt_reset_counters": (i32, [vp]), "rt_set_counting": (i32, [vp, i32]),
+        "rt_set_stripes": (i32, [vp, u32, u32, u32]), "rt_accum_device_ptr": (vp, [vp]),
+        "rt_set_stream": (i32, [vp, vp]),
+        "rt_kernel_time_ms": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(u32)]),
+        "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path == _build.RT_LIB:
+        _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "rt_create rt_destroy rt_last_error rt_set_pipeline rt_resize rt_reset_accum rt_upload_textures rt_upload "
+    "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_present rt_capture "
+    "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
+    "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
+    "rt_set_kernel_timing rt_device_count").split()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class WebGPURenderer:
+    """`new WebGPURenderer(canvas)` + `await init()` (WebGPURenderer.ts:17-32).  The canvas
+    argument of the reference becomes a device ordinal; width/height come from updateScreenSize."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.ctx = self.L.rt_create(int(device))
+        if not self.ctx:
+            msg = self.L.rt_last_error(None)
+            raise RendererError("rt_create(%d) failed: %s" % (device, msg.decode() if msg else "unknown"))
+        self.width = self.height = 0
+        self._capture_buf = None  # reused between captures like readbackResultBuffer (WebGPUContext.ts:82-89)
+
+    def __del__(self):
+        self.destroy()
+
+    def destroy(self):
+        if getattr(self, "ctx", None):
+            self.L.rt_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.L.rt_last_error(self.ctx)
+            raise RendererError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+        return rc
+
+    # ---- reference surface ----
+    def init(self):
+        return None
+
+    def buildPipeline(self, depth, spp):
+        self._check(self.L.rt_set_pipeline(self.ctx, int(depth), int(spp)), "buildPipeline")
+
+    def updateScreenSize(self, width, height):
+        self.width, self.height = int(width), int(height)
+        self._check(self.L.rt_resize(self.ctx, self.width, self.height), "updateScreenSize")
+
+    def resetAccumulation(self):
+        self._check(self.L.rt_reset_accum(self.ctx), "resetAccumulation")
+
+    def loadTexturesFromWorld(self, bridge):
+        n = bridge.textureCount
+        if n == 0:
+            self._check(self.L.rt_upload_textures(self.ctx, None, 0), "loadTexturesFromWorld")
+            return
+        layers = np.ascontiguousarray(np.stack([bridge.getTextureRGBA(i) for i in range(n)]), dtype=np.uint8)
+        self._check(self.L.rt_upload_textures(self.ctx, _ptr(layers), n), "loadTexturesFromWorld")
+
+    def updateBuffer(self, kind, data):
+        a = np.ascontiguousarray(data)
+        rc = self._check(self.L.rt_upload(self.ctx, _KINDS[kind], _ptr(a), a.nbytes), "updateBuffer(%s)" % kind)
+        return rc == RT_REALLOCATED
+
+    def updateCombinedGeometry(self, v, n, uv):
+        v, n, uv = (np.ascontiguousarray(x, dtype=np.float32) for x in (v, n, uv))
+        rc = self._check(self.L.rt_upload_geometry(self.ctx, _ptr(v), _ptr(n), _ptr(uv), v.size // 4),
+                         "updateCombinedGeometry")
+        return rc == RT_REALLOCATED
+
+    def updateCombinedBVH(self, tlas, blas):
+        tlas, blas = (np.ascontiguousarray(x, dtype=np.float32) for x in (tlas, blas))
+        rc = self._check(self.L.rt_upload_bvh(self.ctx, _ptr(tlas), tlas.size // 8, _ptr(blas), blas.size // 8),
+                         "updateCombinedBVH")
+        return rc == RT_REALLOCATED
+
+    def updateSceneUniforms(self, cameraData, frameCount, lightCount):
+        cam = np.ascontiguousarray(cameraData, dtype=np.float32)
+        if cam.size != 24:
+            raise ValueError("cameraData must hold 24 floats")
+        self._check(self.L.rt_set_scene(self.ctx, _ptr(cam), int(frameCount), int(lightCount)), "updateSceneUniforms")
+
+    def recreateBindGroup(self):
+        self.L.rt_recreate_bind_group(self.ctx)
+
+    def compute(self, frameCount):
+        return self._check(self.L.rt_compute(self.ctx, int(frameCount)), "compute")
+
+    def present(self):
+        return self._check(self.L.rt_present(self.ctx), "present")
+
+    def captureFrame(self):
+        if not self.width:
+            raise RendererError("No render target")  # WebGPUContext.ts:43
+        n = self.width * self.height * 4
+        if self._capture_buf is None or self._capture_buf.size != n:
+            self._capture_buf = np.empty(n, dtype=np.uint8)
+        self._check(self.L.rt_capture(self.ctx, _ptr(self._capture_buf), n), "captureFrame")
+        return {"data": self._capture_buf.reshape(self.height, self.width, 4),
+                "width": self.width, "height": self.height}
+
+    def sync(self):
+        """`await renderer.device.queue.onSubmittedWorkDone()`"""
+        self._check(self.L.rt_sync(self.ctx), "sync")
+
+    # ---- additions (parity, checkpoint/resume, sharding, measurement) ----
+    def readAccum(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self.L.rt_read_accum(self.ctx, _ptr(out), out.nbytes), "readAccum")
+        return out
+
+    def writeAccum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        self._check(self.L.rt_write_accum(self.ctx, _ptr(a), a.nbytes), "writeAccum")
+
+    def readGBuffer(self):
+        alb = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        nid = np.empty((self.height, self.width, 4), dtype=np.float32)
+        dep = np.empty((self.height, self.width), dtype=np.float32)
+        self._check(self.L.rt_read_gbuffer(self.ctx, _ptr(alb), _ptr(nid), _ptr(dep)), "readGBuffer")
+        return alb, nid, dep
+
+    def readHistory(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint16)
+        self._check(self.L.rt_read_history(self.ctx, _ptr(out), out.nbytes), "readHistory")
+        return out
+
+    def readUniforms(self):
+        out = np.empty(256, dtype=np.uint8)
+        self._check(self.L.rt_read_uniforms(self.ctx, _ptr(out)), "readUniforms")
+        return out
+
+    def getCounters(self):
+        out = np.zeros(6, dtype=np.uint64)
+        self._check(self.L.rt_get_counters(self.ctx, _ptr(out)), "getCounters")
+        return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+    def resetCounters(self):
+        self._check(self.L.rt_reset_counters(self.ctx), "resetCounters")
+
+    def setCounting(self, detailed):
+        self._check(self.L.rt_set_counting(self.ctx, 1 if detailed else 0), "setCounting")
+
+    def setStripes(self, stripe_rows, rank, count):
+        self._check(self.L.rt_set_stripes(self.ctx, int(stripe_rows), int(rank), int(count)), "setStripes")
+
+    def accumDevicePtr(self):
+        return self.L.rt_accum_device_ptr(self.ctx)
+
+    def setStream(self, hip_stream_handle):
+        self._check(self.L.rt_set_stream(self.ctx, ctypes.c_void_p(hip_stream_handle)), "setStream")
+
+    def setKernelTiming(self, enabled):
+        self._check(self.L.rt_set_kernel_timing(self.ctx, 1 if enabled else 0), "setKernelTiming")
+
+    def kernelTimeMs(self):
+        pt, pv, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint32()
+        self._check(self.L.rt_kernel_time_ms(self.ctx, ctypes.byref(pt), ctypes.byref(pv), ctypes.byref(n)),
+                    "kernelTimeMs")
+        return {"pathtrace_ms": pt.value, "primary_ms": pv.value, "launches": n.value}
+
+
+def upload_scene(renderer, bridge, width, height):
+    """The reference's scene-load sequence (src/main.ts:51-67,99-116): textures, geometry, BVH,
+    topology, instances, lights, draw commands, uniforms, then resolution + reset.
+    Works for any object with the WebGPURenderer method surface (the oracle binding too)."""
+    renderer.loadTexturesFromWorld(bridge)
+    renderer.updateCombinedGeometry(bridge.vertices, bridge.normals, bridge.uvs)
+    renderer.updateCombinedBVH(bridge.tlas, bridge.blas)
+    renderer.updateBuffer("topology", bridge.mesh_topology)
+    renderer.updateBuffer("instance", bridge.instances)
+    renderer.updateBuffer("lights", bridge.lights)
+    renderer.updateBuffer("draw_commands", bridge.draw_commands)
+    renderer.updateScreenSize(width, height)
+    bridge.updateCamera(width, height)
+    renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount)
+    renderer.recreateBindGroup()
+    renderer.resetAccumulation()

@@ -1,0 +1,146 @@
+"""WorldBridge — host-side mirror of src/world-bridge.ts over the native scene compiler.
+
+The reference's WorldBridge is an async proxy to a Web Worker that owns the WASM `World`
+(src/world-bridge.ts:4-216, src/worker/wasm-worker.ts).  Here the `World` is the C++ scene
+compiler behind include/mi355scene.h and calls are synchronous; the getter names, array
+dtypes and element strides are the reference's (src/worker/protocol.ts:14-44).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+_F32P = ctypes.POINTER(ctypes.c_float)
+_U32P = ctypes.POINTER(ctypes.c_uint32)
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.SCENE_LIB
+    if not os.path.exists(path):
+        _build.build_scene()
+    lib = ctypes.CDLL(path)
+    lib.ms_world_create.restype = ctypes.c_void_p
+    lib.ms_world_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.ms_world_destroy.argtypes = [ctypes.c_void_p]
+    lib.ms_last_error.restype = ctypes.c_char_p
+    lib.ms_world_update.argtypes = [ctypes.c_void_p, ctypes.c_float]
+    lib.ms_world_update_camera.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    for name in ("vertices", "normals", "uvs", "tlas", "blas", "instances", "camera"):
+        f = getattr(lib, "ms_world_" + name)
+        f.restype = _F32P
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    for name in ("mesh_topology", "lights", "draw_commands"):
+        f = getattr(lib, "ms_world_" + name)
+        f.restype = _U32P
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.ms_world_texture_count.restype = ctypes.c_size_t
+    lib.ms_world_texture_count.argtypes = [ctypes.c_void_p]
+    lib.ms_world_texture_rgba.restype = ctypes.POINTER(ctypes.c_uint8)
+    lib.ms_world_texture_rgba.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    _lib = lib
+    return lib
+
+
+class WorldBridge:
+    """Same data accessors as the reference class (world-bridge.ts:172-205)."""
+
+    def __init__(self):
+        self._lib = _load()
+        self._world = None
+        self._cache = {}
+        self.hasNewData = False
+        self.hasNewGeometry = False
+        self._last_wh = (-1, -1)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_world", None):
+            self._lib.ms_world_destroy(self._world)
+            self._world = None
+
+    # world-bridge.ts:109-130
+    def loadScene(self, sceneName, objSource=None, glbData=None):
+        if glbData is not None:
+            raise NotImplementedError("glTF/GLB input is out of scope (SURVEY.md §2)")
+        self.close()
+        obj = objSource.encode() if isinstance(objSource, str) else objSource
+        w = self._lib.ms_world_create(sceneName.encode(), obj)
+        if not w:
+            raise ValueError(self._lib.ms_last_error().decode())
+        self._world = w
+        self._last_wh = (-1, -1)
+        self._refresh()
+        self.hasNewData = True
+        self.hasNewGeometry = True
+
+    # world-bridge.ts:141-145
+    def update(self, time):
+        self._lib.ms_world_update(self._world, float(time))
+        self._refresh()
+        self.hasNewData = True
+        self.hasNewGeometry = True
+
+    # world-bridge.ts:150-161
+    def updateCamera(self, width, height):
+        if self._last_wh == (width, height):
+            return
+        self._last_wh = (width, height)
+        self._lib.ms_world_update_camera(self._world, float(width), float(height))
+        self._cache["camera"] = self._get("camera", np.float32)
+
+    def _get(self, name, dtype):
+        n = ctypes.c_size_t()
+        p = getattr(self._lib, "ms_world_" + name)(self._world, ctypes.byref(n))
+        if n.value == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).astype(dtype, copy=True)
+
+    def _refresh(self):
+        for name in ("vertices", "normals", "uvs", "tlas", "blas", "instances", "camera"):
+            self._cache[name] = self._get(name, np.float32)
+        for name in ("mesh_topology", "lights", "draw_commands"):
+            self._cache[name] = self._get(name, np.uint32)
+
+    vertices = property(lambda s: s._cache["vertices"])
+    normals = property(lambda s: s._cache["normals"])
+    uvs = property(lambda s: s._cache["uvs"])
+    mesh_topology = property(lambda s: s._cache["mesh_topology"])
+    tlas = property(lambda s: s._cache["tlas"])
+    blas = property(lambda s: s._cache["blas"])
+    instances = property(lambda s: s._cache["instances"])
+    lights = property(lambda s: s._cache["lights"])
+    draw_commands = property(lambda s: s._cache["draw_commands"])
+    cameraData = property(lambda s: s._cache["camera"])
+
+    @property
+    def lightCount(self):
+        return len(self._cache["lights"]) // 2
+
+    @property
+    def hasWorld(self):
+        return self._world is not None and len(self._cache.get("vertices", ())) > 0
+
+    @property
+    def textureCount(self):
+        return int(self._lib.ms_world_texture_count(self._world)) if self._world else 0
+
+    def getTextureRGBA(self, index):
+        """Decoded 1024x1024 RGBA8 layer (synthetic scenes). The reference returns encoded
+        image bytes (world-bridge.ts:101-106) and lets the browser decode; decoding is out of scope."""
+        p = self._lib.ms_world_texture_rgba(self._world, index)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(1024, 1024, 4)).copy()
+
+    def printStats(self):  # world-bridge.ts:207-215 (with the real strides)
+        return "V=%d, Topo=%d, I=%d, TLAS=%d, BLAS=%d, Lights=%d" % (
+            len(self.vertices) // 4, len(self.mesh_topology) // 20, len(self.instances) // 36,
+            len(self.tlas) // 8, len(self.blas) // 8, self.lightCount)
