@@ -1,0 +1,161 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact accumulation buffer / G-buffer / history / RGBA8 output and
+identical ray counters (north_star tolerance is 1e-4 relative per channel; bit-exact implies it)."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gpu_renderer(W):
+    """A fresh context per test: totalFrames (the Halton jitter index) is renderer-lifetime state
+    (WebGPURenderer.ts:15,89), so parity with a fresh oracle needs a fresh renderer."""
+    W._build.build_rt()
+    r = W.WebGPURenderer(0)
+    yield r
+    r.destroy()
+
+
+CASES = [
+    # scene, w, h, depth, spp, frames
+    ("cornell", 128, 128, 4, 1, (1, 2, 3, 4)),          # BASELINE config 1, reduced resolution
+    ("cornell", 67, 45, 8, 1, (1, 2)),                   # ragged size: partial 8x8 tiles
+    ("cornell", 64, 64, 8, 4, (1, 2)),                   # SPP > 1 inside one dispatch
+    ("cornell", 64, 64, 1, 1, (1,)),                     # MAX_DEPTH = 1: no extension rays
+    ("viewer_diamond", 160, 90, 8, 1, (1, 2, 3)),        # config 2: metal floor + 2 instances
+    ("special", 96, 72, 8, 1, (1, 2)),                   # dielectric box + metal + 528 light triangles
+    ("mixed", 96, 64, 10, 1, (1, 2)),                    # thin lens (defocus 0.3), GGX, nested dielectrics
+    ("mesh", 96, 64, 8, 1, (1, 2)),                      # OBJ cube instances, dielectric, big sphere light
+    ("instanced1000", 96, 54, 8, 1, (1, 2)),             # config 3: 1001 instances, 2001-node TLAS
+    ("sponza_like", 64, 36, 8, 1, (1, 2)),               # config 4: 263k tris, 8 textures, metal-rough maps
+    ("glass_blob", 48, 27, 16, 1, (1, 2)),               # config 5: 205k-tri dielectric, depth 16
+]
+
+
+@pytest.mark.parametrize("scene,w,h,depth,spp,frames", CASES)
+def test_pathtrace_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, spp, frames):
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(gpu_renderer, W, b, w, h, depth, spp, frames, present=False)
+    pu.drive(cpu, W, b, w, h, depth, spp, frames, present=False)
+    pu.assert_parity(gpu_renderer, cpu, check_output=False)
+    c = gpu_renderer.getCounters()
+    assert c["primary_rays"] == w * h * len(frames)
+
+
+@pytest.mark.parametrize("scene,w,h,depth,frames", [
+    ("cornell", 96, 96, 4, tuple(range(1, 21))),   # crosses frame_count 16 -> 17 (bilinear un-jitter -> nearest, k = 60)
+    ("viewer_diamond", 80, 45, 8, (1, 2, 3)),
+    ("cornell", 33, 21, 4, (1, 2)),                 # ragged size for the 16x16 post blocks
+])
+def test_present_parity_live_loop(W, oracle_lib, gpu_renderer, scene, w, h, depth, frames):
+    """compute(); present() every frame exactly like the live loop (main.ts:172-173)."""
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(gpu_renderer, W, b, w, h, depth, 1, frames, present=True)
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=True)
+    pu.assert_parity(gpu_renderer, cpu, check_output=True)
+
+
+def test_recorder_semantics_frame_count_from_zero(W, oracle_lib, gpu_renderer):
+    """VideoRecorder passes frame_count = 0, 1, 2, ... (VideoRecorder.ts:278-280): frames 0 and 1 both
+    overwrite, and the post pass at frame 0 has alpha = 1/0."""
+    b = pu.bridge_for(W, "cornell")
+    cpu = oracle_lib.OracleRenderer()
+    for r in (gpu_renderer, cpu):
+        pu.drive(r, W, b, 64, 64, 4, 1, (0, 1, 2, 3), present=False)
+    pu.assert_parity(gpu_renderer, cpu, check_output=False)
+    acc = gpu_renderer.readAccum()
+    assert acc[..., 3].max() == 3.0  # N-1 samples accumulated
+
+
+def test_accumulation_round_trip_and_reset(W, gpu_renderer):
+    b = pu.bridge_for(W, "cornell")
+    pu.drive(gpu_renderer, W, b, 64, 48, 4, 1, (1, 2), present=False)
+    acc = gpu_renderer.readAccum()
+    gpu_renderer.resetAccumulation()
+    assert not gpu_renderer.readAccum().any()
+    gpu_renderer.writeAccum(acc)  # checkpoint / resume
+    gpu_renderer.compute(3)
+    resumed = gpu_renderer.readAccum()
+    fresh = W.WebGPURenderer(0)
+    pu.drive(fresh, W, b, 64, 48, 4, 1, (1, 2, 3), present=False)
+    assert np.array_equal(resumed.view(np.uint32), fresh.readAccum().view(np.uint32))
+    fresh.destroy()
+
+
+def test_stripes_partition_is_bitwise_identical(W, gpu_renderer):
+    """Interleaved row stripes rendered separately and summed == the full render."""
+    b = pu.bridge_for(W, "cornell")
+    w, h, frames = 80, 72, (1, 2, 3)
+    pu.drive(gpu_renderer, W, b, w, h, 4, 1, frames, present=False)
+    full = gpu_renderer.readAccum()
+    full_counts = gpu_renderer.getCounters()
+    total = np.zeros_like(full)
+    counts = {}
+    n = 3
+    for rank in range(n):
+        r = W.WebGPURenderer(0)
+        r.setStripes(16, rank, n)
+        pu.drive(r, W, b, w, h, 4, 1, frames, present=False)
+        part = r.readAccum()
+        rows = (np.arange(h) // 16) % n == rank
+        assert not part[~rows].any()  # nothing written outside the owned stripes
+        total += part
+        for k, v in r.getCounters().items():
+            counts[k] = counts.get(k, 0) + v
+        r.destroy()
+    gpu_renderer.setStripes(0, 0, 1)
+    assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+    assert counts == full_counts
+
+
+def test_update_buffer_reports_reallocation(W, gpu_renderer):
+    """updateBuffer returns needsRebind only when the buffer had to grow (1.5x policy)."""
+    r = W.WebGPURenderer(0)
+    small = np.zeros(20 * 10, dtype=np.uint32)
+    assert r.updateBuffer("topology", small) is True        # first allocation
+    assert r.updateBuffer("topology", small) is False       # fits
+    assert r.updateBuffer("topology", np.zeros(20 * 14, dtype=np.uint32)) is False   # within the 1.5x slack
+    assert r.updateBuffer("topology", np.zeros(20 * 40, dtype=np.uint32)) is True    # must grow
+    r.destroy()
+
+
+def test_passes_skip_silently_when_not_ready(W):
+    """Like the reference passes, compute()/present() do nothing (and do not throw) before resources exist."""
+    r = W.WebGPURenderer(0)
+    assert r.compute(1) == 2  # RT_SKIPPED
+    assert r.present() == 2
+    with pytest.raises(W.RendererError):
+        r.captureFrame()
+    r.destroy()
+
+
+def test_full_size_properties_1080p(W, oracle_lib, gpu_renderer):
+    """BASELINE metric size (1920x1080, depth 8): properties that need no oracle run —
+    sample count, finiteness, energy bounds, determinism and stripe-sum identity."""
+    b = pu.bridge_for(W, "cornell")
+    w, h = 1920, 1080
+    pu.drive(gpu_renderer, W, b, w, h, 8, 1, (1, 2, 3, 4), present=True, detailed=False)
+    a1 = gpu_renderer.readAccum()
+    out1 = gpu_renderer.captureFrame()["data"].copy()
+    c1 = gpu_renderer.getCounters()
+    assert np.isfinite(a1).all() and (a1[..., 3] == 4.0).all() and (a1[..., :3] >= 0).all()
+    assert a1[..., :3].max() <= 4 * 20.0 * 8  # no sample can exceed light radiance x depth
+    assert c1["primary_rays"] == w * h * 4
+    assert 0 < c1["shadow_rays"] <= c1["extension_rays"] + c1["primary_rays"]
+    again = W.WebGPURenderer(0)
+    pu.drive(again, W, b, w, h, 8, 1, (1, 2, 3, 4), present=True, detailed=False)
+    assert np.array_equal(a1.view(np.uint32), again.readAccum().view(np.uint32))  # deterministic
+    assert np.array_equal(out1, again.captureFrame()["data"])
+    assert again.getCounters() == c1
+    again.destroy()
+    # oracle band at full size: the CPU renders only rows [512, 520) of the same 1080p frames
+    cpu = oracle_lib.OracleRenderer()
+    cpu.setStripes(8, 64, 135)
+    pu.drive(cpu, W, b, w, h, 8, 1, (1, 2, 3, 4), present=False)
+    band = cpu.readAccum()[512:520]
+    assert np.array_equal(band.view(np.uint32), a1[512:520].view(np.uint32))

@@ -1,0 +1,55 @@
+// device_scene.h — device-side view of the scene as the HIP kernels read it.
+//
+// The bridge arrays arrive in the reference's layouts (include/mi355rt_layout.h).  At
+// upload time they are re-laid-out once on the GPU into gather-friendly records (all
+// bit-exact: only f32 subtractions the reference shader would perform per test, or
+// pure permutations):
+//
+//   nodes      2 x float4 / node   {min.xyz, skip} {max.xyz, data}           (unchanged, 32 B)
+//   tri_geom   3 x float4 / tri    {v0, _} {e1 = v1-v0, _} {e2 = v2-v0, _}   (48 B instead of the
+//              80-B topology row + 3 dependent 16-B position gathers, Raytracer.wgsl:476-477)
+//   inst_trav  4 x float4 / inst   rows 0..2 of the inverse matrix (so M*p is 3 dot-like rows),
+//              {blas_node_offset, inv[3], inv[7], inv[11]}                    (64 B instead of 144 B)
+//   topo/pos/nrm/uv/inst/lights    raw arrays, read once per shaded hit
+#ifndef MI355RT_DEVICE_SCENE_H
+#define MI355RT_DEVICE_SCENE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355rt_layout.h"
+#include "../../include/mi355rt_math.h"
+
+struct DevScene {
+  const float4* nodes;      // 2 per node, TLAS ++ BLAS
+  const float4* tri_geom;   // 3 per triangle
+  const float4* inst_trav;  // 4 per instance
+  const float4* topo;       // 5 per triangle (raw MeshTopology rows)
+  const float4* pos;        // 1 per vertex
+  const float4* nrm;        // 1 per vertex
+  const float2* uv;         // 1 per vertex
+  const float4* inst;       // 9 per instance (raw Instance)
+  const uint2* lights;      // LightRef
+  const uint8_t* tex;       // layers x 1024 x 1024 x 4, or nullptr => 1x1 white default
+  uint32_t tex_layers;
+  uint32_t n_lights;        // elements in `lights` (for the robust-access clamp)
+};
+
+struct DevFrame {
+  float4* accum;        // W*H float4
+  uint32_t* albedo;     // W*H rgba8 (render target: G-buffer albedo, later post output)
+  float4* normal_id;    // W*H rgba32f
+  float* depth;         // W*H f32
+  uint64_t* counters;   // 6 x u64
+  uint32_t max_depth, spp;
+  uint32_t stripe_rows, stripe_rank, stripe_count;
+};
+
+struct DevPost {
+  const float4* accum;
+  const ushort4* history_in;  // rgba16f, previous frame
+  ushort4* history_out;       // rgba16f, current frame
+  uint32_t* out_rgba8;        // render target
+};
+
+#endif

@@ -1,0 +1,913 @@
+// kernels.hip.h — hand-written gfx950 kernels of the path-tracing hot path.
+//
+//   k_prepare_tris / k_prepare_instances   upload-time re-layout (device_scene.h)
+//   k_primary_visibility   replaces the hardware-raster G-buffer pass (Rasterizer.wgsl:81-173,
+//                          RasterizerPass.ts:97-140): one closest-hit cast per pixel
+//   k_pathtrace            Raytracer.wgsl `main` + ray_color (:607-819)
+//   k_postprocess          PostProcess.wgsl `main` (:103-176)
+//
+// All arithmetic is unfused IEEE f32 (-ffp-contract=off) with the builtin semantics of
+// include/mi355rt_math.h, in the evaluation order of the WGSL source, so that every path
+// takes the same branches as the CPU oracle and results agree bit for bit.
+#ifndef MI355RT_KERNELS_HIP_H
+#define MI355RT_KERNELS_HIP_H
+
+#include "device_scene.h"
+
+#define RT_T_MIN 0.001f
+#define RT_T_MAX 1e30f
+#define RT_COUNTER_SHARDS 1024
+
+namespace rtk {
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ rt3 xyz(float4 v) { return rt3_make(v.x, v.y, v.z); }
+
+struct LaneCounters {
+  uint32_t primary, extension, shadow, nodes, tris, shaded;
+};
+
+// rows 0..2 of a column-major matrix M: (M*vec4(p,1)).xyz, (M*vec4(d,0)).xyz and (vec4(n,0)*M).xyz
+struct InvRows {
+  float4 r0, r1, r2, tail;  // tail = {bitcast(blas_node_offset), M[3], M[7], M[11]}
+};
+__device__ __forceinline__ InvRows load_inv_rows(const DevScene& S, uint32_t inst) {
+  InvRows m;
+  m.r0 = S.inst_trav[4 * inst + 0];
+  m.r1 = S.inst_trav[4 * inst + 1];
+  m.r2 = S.inst_trav[4 * inst + 2];
+  m.tail = S.inst_trav[4 * inst + 3];
+  return m;
+}
+__device__ __forceinline__ rt3 mul_point(const InvRows& m, rt3 p) {
+  return rt3_make(m.r0.x * p.x + m.r0.y * p.y + m.r0.z * p.z + m.r0.w * 1.0f,
+                  m.r1.x * p.x + m.r1.y * p.y + m.r1.z * p.z + m.r1.w * 1.0f,
+                  m.r2.x * p.x + m.r2.y * p.y + m.r2.z * p.z + m.r2.w * 1.0f);
+}
+__device__ __forceinline__ rt3 mul_dir(const InvRows& m, rt3 d) {
+  return rt3_make(m.r0.x * d.x + m.r0.y * d.y + m.r0.z * d.z + m.r0.w * 0.0f,
+                  m.r1.x * d.x + m.r1.y * d.y + m.r1.z * d.z + m.r1.w * 0.0f,
+                  m.r2.x * d.x + m.r2.y * d.y + m.r2.z * d.z + m.r2.w * 0.0f);
+}
+__device__ __forceinline__ rt3 normal_to_world(const InvRows& m, rt3 n) {  // (vec4(n,0) * inv).xyz
+  return rt3_make(n.x * m.r0.x + n.y * m.r1.x + n.z * m.r2.x + 0.0f * m.tail.y,
+                  n.x * m.r0.y + n.y * m.r1.y + n.z * m.r2.y + 0.0f * m.tail.z,
+                  n.x * m.r0.z + n.y * m.r1.z + n.z * m.r2.z + 0.0f * m.tail.w);
+}
+
+// ------------------------------------------------------------------- textures
+// textureSampleLevel(tex, smp, uv, layer, 0): bilinear / repeat / level 0 / unorm / no sRGB
+__device__ __forceinline__ rt3 texel_rgb(const uint8_t* base, int x, int y) {
+  uint32_t p = *reinterpret_cast<const uint32_t*>(base + ((size_t)y * RT_TEX_SIZE + (size_t)x) * 4);
+  return rt3_make(rt_from_unorm8(p & 255u), rt_from_unorm8((p >> 8) & 255u), rt_from_unorm8((p >> 16) & 255u));
+}
+__device__ rt3 sample_tex(const DevScene& S, rt2 tuv, int32_t layer) {
+  if (S.tex_layers == 0u) return rt3_splat(1.0f);
+  if (layer < 0) layer = 0;
+  if ((uint32_t)layer >= S.tex_layers) layer = (int32_t)S.tex_layers - 1;
+  const int N = RT_TEX_SIZE;
+  float x = tuv.x * (float)N - 0.5f, y = tuv.y * (float)N - 0.5f;
+  float fx0 = rt_floor(x), fy0 = rt_floor(y);
+  float fx = x - fx0, fy = y - fy0;
+  int ix = rt_f2i32_sat(fx0), iy = rt_f2i32_sat(fy0);
+  int x0 = (int)((uint32_t)ix & (uint32_t)(N - 1)), x1 = (int)((uint32_t)(ix + 1) & (uint32_t)(N - 1));
+  int y0 = (int)((uint32_t)iy & (uint32_t)(N - 1)), y1 = (int)((uint32_t)(iy + 1) & (uint32_t)(N - 1));
+  const uint8_t* base = S.tex + (size_t)layer * N * N * 4;
+  rt3 top = rt_mix3(texel_rgb(base, x0, y0), texel_rgb(base, x1, y0), fx);
+  rt3 bot = rt_mix3(texel_rgb(base, x0, y1), texel_rgb(base, x1, y1), fx);
+  return rt_mix3(top, bot, fy);
+}
+
+// ------------------------------------------------------------------------ RNG
+__device__ __forceinline__ uint32_t init_rng(uint32_t pixel_idx, uint32_t frame) {  // Raytracer.wgsl:178-183
+  uint32_t s = pixel_idx + frame * 719393u;
+  s ^= 2747636419u; s *= 2654435769u; s ^= (s >> 16);
+  s *= 2654435769u; s ^= (s >> 16); s *= 2654435769u;
+  return s;
+}
+__device__ __forceinline__ float rand_pcg(uint32_t& state) {  // :185-189
+  uint32_t old = state;
+  state = old * 747796405u + 2891336453u;
+  uint32_t word = (state >> ((old >> 28) + 4u)) ^ state;
+  // f32(u32) rounds to nearest even; 4294967295.0 is 2^32 as an f32 literal: the division is an exact scaling
+  return (float)((word >> 22) ^ word) * 2.3283064365386962890625e-10f;
+}
+
+// ------------------------------------------------------------------ traversal
+struct LocalRay {
+  rt3 o, d, inv_d, o_inv_d;
+};
+__device__ __forceinline__ LocalRay make_ray(rt3 o, rt3 d) {  // :83-86
+  LocalRay r;
+  r.o = o;
+  r.d = d;
+  r.inv_d = rt3_splat(1.0f) / d;
+  r.o_inv_d = o * r.inv_d;
+  return r;
+}
+// slab test (:433-441): true when tm_near <= tm_far
+__device__ __forceinline__ bool hit_box(float4 lo, float4 hi, const LocalRay& r, float t_min, float t_max) {
+  float t1x = lo.x * r.inv_d.x - r.o_inv_d.x, t2x = hi.x * r.inv_d.x - r.o_inv_d.x;
+  float t1y = lo.y * r.inv_d.y - r.o_inv_d.y, t2y = hi.y * r.inv_d.y - r.o_inv_d.y;
+  float t1z = lo.z * r.inv_d.z - r.o_inv_d.z, t2z = hi.z * r.inv_d.z - r.o_inv_d.z;
+  float nx = rt_min(t1x, t2x), ny = rt_min(t1y, t2y), nz = rt_min(t1z, t2z);
+  float fx = rt_max(t1x, t2x), fy = rt_max(t1y, t2y), fz = rt_max(t1z, t2z);
+  float tm_near = rt_max(t_min, rt_max(nx, rt_max(ny, nz)));
+  float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
+  return tm_near <= tm_far;
+}
+// Möller–Trumbore on the precomputed (v0, e1, e2) record (:443-453); returns t or -1
+__device__ __forceinline__ float hit_tri(float4 g0, float4 g1, float4 g2, const LocalRay& r, float t_min,
+                                         float t_max) {
+  rt3 v0 = xyz(g0), e1 = xyz(g1), e2 = xyz(g2);
+  rt3 h = rt_cross(r.d, e2);
+  float a = rt_dot(e1, h);
+  if (rt_abs(a) < 1e-6f) return -1.0f;
+  float f = 1.0f / a;
+  rt3 s = r.o - v0;
+  float u = f * rt_dot(s, h);
+  if (u < 0.0f || u > 1.0f) return -1.0f;
+  rt3 q = rt_cross(s, e1);
+  float v = f * rt_dot(r.d, q);
+  if (v < 0.0f || u + v > 1.0f) return -1.0f;
+  float t = f * rt_dot(e2, q);
+  return (t > t_min && t < t_max) ? t : -1.0f;
+}
+
+struct Hit {
+  float t;
+  int32_t tri;   // -1 = none (the reference carries the id as f32; identical below 2^24 triangles)
+  int32_t inst;  // -1 = none
+};
+
+// closest hit: intersect_tlas + intersect_blas (:455-528)
+template <bool COUNT>
+__device__ Hit trace_closest(const DevScene& S, uint32_t blas_base, rt3 o, rt3 d, float t_min, float t_max,
+                             LaneCounters& c) {
+  Hit res;
+  res.t = t_max;
+  res.tri = -1;
+  res.inst = -1;
+  if (blas_base == 0u) return res;
+  LocalRay rw = make_ray(o, d);
+  uint32_t curr = 0u;
+  const uint32_t end_node = rt_f2u(S.nodes[0].w);
+  while (curr < end_node) {
+    float4 lo = S.nodes[2 * curr], hi = S.nodes[2 * curr + 1];
+    if (COUNT) c.nodes++;
+    uint32_t next = rt_f2u(lo.w);
+    if (hit_box(lo, hi, rw, t_min, res.t)) {
+      uint32_t data = rt_f2u(hi.w);
+      if (data != 0u) {
+        uint32_t inst = data >> 3;
+        InvRows m = load_inv_rows(S, inst);
+        LocalRay rl = make_ray(mul_point(m, o), mul_dir(m, d));
+        const uint32_t start = blas_base + rt_f2u(m.tail.x);
+        const uint32_t bend = start + rt_f2u(S.nodes[2 * start].w);
+        uint32_t bc = start;
+        float closest = res.t;
+        int32_t best = -1;
+        while (bc < bend) {
+          float4 blo = S.nodes[2 * bc], bhi = S.nodes[2 * bc + 1];
+          if (COUNT) c.nodes++;
+          uint32_t bnext = start + rt_f2u(blo.w);
+          if (hit_box(blo, bhi, rl, t_min, closest)) {
+            uint32_t bdata = rt_f2u(bhi.w);
+            if (bdata != 0u) {
+              uint32_t first = bdata >> 3, count = bdata & 7u;
+              for (uint32_t i = 0; i < count; i++) {
+                uint32_t tri = first + i;
+                if (COUNT) c.tris++;
+                float t = hit_tri(S.tri_geom[3 * tri], S.tri_geom[3 * tri + 1], S.tri_geom[3 * tri + 2], rl, t_min,
+                                  closest);
+                if (t > 0.0f) {
+                  closest = t;
+                  best = (int32_t)tri;
+                }
+              }
+            } else {
+              bnext = bc + 1u;
+            }
+          }
+          bc = bnext;
+        }
+        if (best >= 0) {
+          res.t = closest;
+          res.tri = best;
+          res.inst = (int32_t)inst;
+        }
+      } else {
+        next = curr + 1u;
+      }
+    }
+    curr = next;
+  }
+  return res;
+}
+
+// any hit: intersect_tlas_shadow + intersect_blas_shadow (:532-600)
+template <bool COUNT>
+__device__ bool trace_any(const DevScene& S, uint32_t blas_base, rt3 o, rt3 d, float t_min, float t_max,
+                          LaneCounters& c) {
+  if (blas_base == 0u) return false;
+  LocalRay rw = make_ray(o, d);
+  uint32_t curr = 0u;
+  const uint32_t end_node = rt_f2u(S.nodes[0].w);
+  while (curr < end_node) {
+    float4 lo = S.nodes[2 * curr], hi = S.nodes[2 * curr + 1];
+    if (COUNT) c.nodes++;
+    uint32_t next = rt_f2u(lo.w);
+    if (hit_box(lo, hi, rw, t_min, t_max)) {
+      uint32_t data = rt_f2u(hi.w);
+      if (data != 0u) {
+        uint32_t inst = data >> 3;
+        InvRows m = load_inv_rows(S, inst);
+        LocalRay rl = make_ray(mul_point(m, o), mul_dir(m, d));
+        const uint32_t start = blas_base + rt_f2u(m.tail.x);
+        const uint32_t bend = start + rt_f2u(S.nodes[2 * start].w);
+        uint32_t bc = start;
+        while (bc < bend) {
+          float4 blo = S.nodes[2 * bc], bhi = S.nodes[2 * bc + 1];
+          if (COUNT) c.nodes++;
+          uint32_t bnext = start + rt_f2u(blo.w);
+          if (hit_box(blo, bhi, rl, t_min, t_max)) {
+            uint32_t bdata = rt_f2u(bhi.w);
+            if (bdata != 0u) {
+              uint32_t first = bdata >> 3, count = bdata & 7u;
+              for (uint32_t i = 0; i < count; i++) {
+                uint32_t tri = first + i;
+                if (COUNT) c.tris++;
+                float t = hit_tri(S.tri_geom[3 * tri], S.tri_geom[3 * tri + 1], S.tri_geom[3 * tri + 2], rl, t_min,
+                                  t_max);
+                if (t > 0.0f) return true;
+              }
+            } else {
+              bnext = bc + 1u;
+            }
+          }
+          bc = bnext;
+        }
+      } else {
+        next = curr + 1u;
+      }
+    }
+    curr = next;
+  }
+  return false;
+}
+
+// -------------------------------------------------------------- surface frame
+// What a bounce needs to know about the hit triangle (Raytracer.wgsl:625-654 and :738-779).
+struct Surface {
+  float hit_t;
+  rt2 tex_uv;
+  rt3 normal;        // shading normal, world space
+  rt3 geom_n;        // geometric normal, world space
+  rt3 albedo;
+  float u_bar, v_bar, w_bar;
+};
+
+struct Bary {
+  float u, v, w, t;
+  rt3 e1, e2;
+};
+// unbounded ray/plane barycentrics of the local-space ray against triangle `tri` (:632-643)
+__device__ __forceinline__ Bary barycentrics(const DevScene& S, uint32_t tri, rt3 lo, rt3 ld) {
+  rt3 v0 = xyz(S.tri_geom[3 * tri]);
+  Bary b;
+  b.e1 = xyz(S.tri_geom[3 * tri + 1]);
+  b.e2 = xyz(S.tri_geom[3 * tri + 2]);
+  rt3 s = lo - v0;
+  rt3 h = rt_cross(ld, b.e2);
+  float f = 1.0f / rt_dot(b.e1, h);
+  b.u = f * rt_dot(s, h);
+  rt3 q = rt_cross(s, b.e1);
+  b.v = f * rt_dot(ld, q);
+  b.w = 1.0f - b.u - b.v;
+  b.t = f * rt_dot(b.e2, q);
+  return b;
+}
+
+__device__ __forceinline__ rt2 pack_normal(rt3 n) {  // Rasterizer.wgsl:71-74
+  float s = 1.0f / (rt_abs(n.x) + rt_abs(n.y) + rt_abs(n.z));
+  rt2 p = rt2_make(n.x * s, n.y * s);
+  if (n.z < 0.0f) {
+    float ox = (1.0f - rt_abs(p.y)) * (p.x >= 0.0f ? 1.0f : -1.0f);
+    float oy = (1.0f - rt_abs(p.x)) * (p.y >= 0.0f ? 1.0f : -1.0f);
+    return rt2_make(ox, oy);
+  }
+  return p;
+}
+__device__ __forceinline__ rt3 unpack_normal(float px, float py) {  // Raytracer.wgsl:121-127
+  rt3 n = rt3_make(px, py, 1.0f - rt_abs(px) - rt_abs(py));
+  float t = rt_saturate(-n.z);
+  n.x += (n.x >= 0.0f) ? -t : t;
+  n.y += (n.y >= 0.0f) ? -t : t;
+  return rt_normalize(n);
+}
+
+// ---------------------------------------------------------------------- BSDFs
+struct Onb {
+  rt3 u, v, w;
+};
+__device__ __forceinline__ Onb build_onb(rt3 n) {  // :207-214
+  float sign = (n.z >= 0.0f) ? 1.0f : -1.0f;
+  float a = -1.0f / (sign + n.z);
+  float b = n.x * n.y * a;
+  Onb o;
+  o.u = rt3_make(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+  o.v = rt3_make(b, sign + n.y * n.y * a, -n.y);
+  o.w = n;
+  return o;
+}
+__device__ __forceinline__ rt3 to_world(const Onb& o, rt3 a) { return a.x * o.u + a.y * o.v + a.z * o.w; }
+
+__device__ __forceinline__ float ggx_d(float n_dot_h, float a2) {  // :236-239
+  float d = (n_dot_h * a2 - n_dot_h) * n_dot_h + 1.0f;
+  return a2 / (RT_PI * d * d);
+}
+__device__ __forceinline__ float ggx_g(float n_dot_v, float n_dot_l, float a2) {  // :241-245
+  float g1_v = 2.0f * n_dot_v / (n_dot_v + rt_sqrt(a2 + (1.0f - a2) * n_dot_v * n_dot_v));
+  float g1_l = 2.0f * n_dot_l / (n_dot_l + rt_sqrt(a2 + (1.0f - a2) * n_dot_l * n_dot_l));
+  return g1_v * g1_l;
+}
+__device__ __forceinline__ float pow5(float x) {
+  float x2 = x * x;
+  return x2 * x2 * x;
+}
+__device__ __forceinline__ rt3 fresnel_schlick(float cos_theta, rt3 f0) {  // :252-254
+  return f0 + (rt3_splat(1.0f) - f0) * pow5(rt_clamp(1.0f - cos_theta, 0.0f, 1.0f));
+}
+__device__ rt3 eval_ggx(rt3 n, rt3 v, rt3 l, float roughness, rt3 f0) {  // :256-269
+  rt3 h = rt_normalize(v + l);
+  float n_dot_v = rt_max(rt_dot(n, v), 1e-4f);
+  float n_dot_l = rt_max(rt_dot(n, l), 1e-4f);
+  float n_dot_h = rt_max(rt_dot(n, h), 1e-4f);
+  float v_dot_h = rt_max(rt_dot(v, h), 1e-4f);
+  float a2 = roughness * roughness;
+  float d = ggx_d(n_dot_h, a2);
+  float g = ggx_g(n_dot_v, n_dot_l, a2);
+  rt3 f = fresnel_schlick(v_dot_h, f0);
+  return (d * g * f) / (4.0f * n_dot_v * n_dot_l);
+}
+
+struct Scatter {
+  rt3 dir;
+  float pdf;
+  rt3 throughput;
+  bool specular;
+};
+__device__ Scatter sample_diffuse(rt3 normal, rt3 albedo, uint32_t& rng) {  // :228-233, :191-199
+  Onb onb = build_onb(normal);
+  float r1 = rand_pcg(rng);
+  float r2 = rand_pcg(rng);
+  float phi = RT_TWO_PI * r1;
+  float cos_theta = rt_sqrt(1.0f - r2);
+  float sin_theta = rt_sqrt(r2);
+  float sp, cp;
+  rt_sincos(phi, &sp, &cp);
+  Scatter s;
+  s.dir = to_world(onb, rt3_make(cp * sin_theta, sp * sin_theta, cos_theta));
+  float c = rt_max(rt_dot(normal, s.dir), 0.0f);
+  s.pdf = c / RT_PI;
+  s.throughput = albedo;
+  s.specular = false;
+  return s;
+}
+__device__ Scatter sample_ggx(rt3 n, rt3 v, float roughness, rt3 f0, uint32_t& rng) {  // :271-306
+  float a = roughness;
+  float ux = rand_pcg(rng);
+  float uy = rand_pcg(rng);
+  float phi = RT_TWO_PI * ux;
+  float cos_theta = rt_sqrt(rt_max(0.0f, (1.0f - uy) / (1.0f + (a * a - 1.0f) * uy)));
+  float sin_theta = rt_sqrt(rt_max(0.0f, 1.0f - cos_theta * cos_theta));
+  float sp, cp;
+  rt_sincos(phi, &sp, &cp);
+  Onb onb = build_onb(n);
+  rt3 h = to_world(onb, rt3_make(sin_theta * cp, sin_theta * sp, cos_theta));
+  rt3 l = rt_reflect(-v, h);
+  Scatter s;
+  if (rt_dot(n, l) <= 0.0f) {
+    s.dir = rt3_splat(0.0f);
+    s.pdf = 0.0f;
+    s.throughput = rt3_splat(0.0f);
+    s.specular = false;
+    return s;
+  }
+  float n_dot_v = rt_max(rt_dot(n, v), 1e-4f);
+  float n_dot_l = rt_max(rt_dot(n, l), 1e-4f);
+  float n_dot_h = rt_max(rt_dot(n, h), 1e-4f);
+  float v_dot_h = rt_max(rt_dot(v, h), 1e-4f);
+  float a2 = a * a;
+  float d = ggx_d(n_dot_h, a2);
+  float g = ggx_g(n_dot_v, n_dot_l, a2);
+  rt3 f = fresnel_schlick(v_dot_h, f0);
+  s.dir = l;
+  s.pdf = (d * n_dot_h) / (4.0f * v_dot_h);
+  s.throughput = rt3_splat(0.0f);
+  if (s.pdf > 1e-6f) s.throughput = (g * f * v_dot_h) / (n_dot_v * n_dot_h);
+  s.specular = roughness < 0.01f;
+  return s;
+}
+__device__ Scatter sample_dielectric(rt3 dir, rt3 normal, float ior, rt3 albedo, uint32_t& rng) {  // :320-339
+  bool front_face = rt_dot(dir, normal) < 0.0f;
+  float ratio = front_face ? (1.0f / ior) : ior;
+  rt3 n = front_face ? normal : -normal;
+  rt3 unit_dir = rt_normalize(dir);
+  float cos_theta = rt_min(rt_dot(-unit_dir, n), 1.0f);
+  float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
+  bool cannot_refract = ratio * sin_theta > 1.0f;
+  bool reflect_it = cannot_refract;
+  if (!reflect_it) {  // short-circuit `||`: the draw happens only when refraction is possible
+    float r0 = (1.0f - ratio) / (1.0f + ratio);
+    r0 = r0 * r0;
+    float refl = r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
+    reflect_it = refl > rand_pcg(rng);
+  }
+  Scatter s;
+  s.dir = reflect_it ? rt_reflect(unit_dir, n) : rt_refract(unit_dir, n, ratio);
+  s.pdf = 1.0f;
+  s.throughput = albedo;
+  s.specular = true;
+  return s;
+}
+
+// ------------------------------------------------------------- light sampling
+struct LightSample {
+  rt3 L, dir;
+  float dist, pdf;
+};
+struct WorldTri {
+  rt3 v0, v1, v2;
+};
+__device__ __forceinline__ WorldTri world_triangle(const DevScene& S, uint32_t tri, uint32_t inst) {
+  float4 idx = S.topo[5 * tri];
+  const float* m = reinterpret_cast<const float*>(&S.inst[9 * inst]);  // forward transform, column-major
+  WorldTri w;
+  w.v0 = rt_mat_mul_point(m, xyz(S.pos[rt_f2u(idx.x)]));
+  w.v1 = rt_mat_mul_point(m, xyz(S.pos[rt_f2u(idx.y)]));
+  w.v2 = rt_mat_mul_point(m, xyz(S.pos[rt_f2u(idx.z)]));
+  return w;
+}
+__device__ LightSample sample_light(const DevScene& S, uint32_t light_count, rt3 hit_p, uint32_t& rng) {  // :345-399
+  LightSample none;
+  none.L = rt3_splat(0.0f);
+  none.dir = rt3_splat(0.0f);
+  none.dist = 0.0f;
+  none.pdf = 0.0f;
+  if (light_count == 0u) return none;
+  uint32_t pick = rt_f2u32_sat(rand_pcg(rng) * (float)light_count);
+  if (pick >= S.n_lights) pick = S.n_lights - 1u;  // robust buffer access clamp (rand can be exactly 1.0)
+  uint2 ref = S.lights[pick];
+  WorldTri w = world_triangle(S, ref.y, ref.x);
+  float r1 = rand_pcg(rng);
+  float r2 = rand_pcg(rng);
+  float sqrt_r1 = rt_sqrt(r1);
+  float u = 1.0f - sqrt_r1;
+  float v = r2 * sqrt_r1;
+  float ww = 1.0f - u - v;
+  rt3 p = w.v0 * u + w.v1 * v + w.v2 * ww;
+  rt3 edge1 = w.v1 - w.v0;
+  rt3 edge2 = w.v2 - w.v0;
+  rt3 cr = rt_cross(edge1, edge2);
+  rt3 n_raw = rt_normalize(cr);
+  float area = rt_length(cr) * 0.5f;
+  rt3 l_dir = p - hit_p;
+  float dist_sq = rt_dot(l_dir, l_dir);
+  float dist = rt_sqrt(dist_sq);
+  rt3 unit_l = l_dir / dist;
+  float cos_l = rt_max(rt_dot(n_raw, -unit_l), 0.0f);
+  if (cos_l < 1e-6f) return none;
+  float4 idx = S.topo[5 * ref.y], d0 = S.topo[5 * ref.y + 1], d2 = S.topo[5 * ref.y + 3];
+  rt3 L = xyz(d0);
+  if (d2.x > -0.5f) {
+    float2 a = S.uv[rt_f2u(idx.x)], b = S.uv[rt_f2u(idx.y)], c = S.uv[rt_f2u(idx.z)];
+    rt2 tuv = rt2_make(a.x, a.y) * u + rt2_make(b.x, b.y) * v + rt2_make(c.x, c.y) * ww;
+    L = L * sample_tex(S, tuv, rt_f2i32_sat(d2.x));
+  }
+  LightSample s;
+  s.L = L;
+  s.dir = unit_l;
+  s.dist = dist;
+  s.pdf = (dist_sq / (cos_l * area)) / (float)light_count;
+  return s;
+}
+__device__ float light_pdf(const DevScene& S, uint32_t light_count, uint32_t tri, uint32_t inst, float t,
+                           rt3 l_dir) {  // :401-421
+  WorldTri w = world_triangle(S, tri, inst);
+  rt3 edge1 = w.v1 - w.v0;
+  rt3 edge2 = w.v2 - w.v0;
+  rt3 cr = rt_cross(edge1, edge2);
+  float area = rt_length(cr) * 0.5f;
+  rt3 normal = rt_normalize(cr);
+  float cos_l = rt_max(rt_dot(normal, -l_dir), 0.0f);
+  if (cos_l < 1e-4f) return 0.0f;
+  float dist_sq = t * t;
+  return (dist_sq / (cos_l * area)) / (float)light_count;
+}
+__device__ __forceinline__ float power_heuristic(float a, float b) {
+  float a2 = a * a, b2 = b * b;
+  return a2 / (a2 + b2);
+}
+
+// ------------------------------------------------------------- counters
+__device__ __forceinline__ uint64_t wave_sum(uint32_t v) {
+  uint64_t s = v;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
+template <bool DETAIL>
+__device__ __forceinline__ void flush_counters(const LaneCounters& c, uint64_t* counters, uint32_t shard) {
+  uint64_t* dst = counters + (size_t)(shard % RT_COUNTER_SHARDS) * 6;
+  uint64_t p = wave_sum(c.primary), e = wave_sum(c.extension), s = wave_sum(c.shadow);
+  uint64_t n = 0, t = 0, h = 0;
+  if (DETAIL) {
+    n = wave_sum(c.nodes);
+    t = wave_sum(c.tris);
+    h = wave_sum(c.shaded);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    if (p) atomicAdd((unsigned long long*)&dst[0], (unsigned long long)p);
+    if (e) atomicAdd((unsigned long long*)&dst[1], (unsigned long long)e);
+    if (s) atomicAdd((unsigned long long*)&dst[2], (unsigned long long)s);
+    if (DETAIL) {
+      atomicAdd((unsigned long long*)&dst[3], (unsigned long long)n);
+      atomicAdd((unsigned long long*)&dst[4], (unsigned long long)t);
+      atomicAdd((unsigned long long*)&dst[5], (unsigned long long)h);
+    }
+  }
+}
+
+__device__ __forceinline__ bool owns_row(const DevFrame& F, uint32_t y) {
+  if (F.stripe_rows == 0u || F.stripe_count <= 1u) return true;
+  return (y / F.stripe_rows) % F.stripe_count == F.stripe_rank;
+}
+
+// One wave = one 8x8 pixel tile (the reference's workgroup shape, RaytracePass.ts:96-103).
+__device__ __forceinline__ bool tile_pixel(const rt_scene_uniforms& U, uint32_t& x, uint32_t& y) {
+  const uint32_t tiles_x = (U.width + 7u) / 8u;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  x = (tile % tiles_x) * 8u + (lane & 7u);
+  y = (tile / tiles_x) * 8u + (lane >> 3);
+  return x < U.width && y < U.height;
+}
+
+// =========================================================== upload-time re-layout
+__global__ void k_prepare_tris(const float4* __restrict__ topo, const float4* __restrict__ pos,
+                               float4* __restrict__ tri_geom, uint32_t n_tris, uint32_t n_verts) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tris) return;
+  float4 idx = topo[5 * i];
+  uint32_t i0 = rt_f2u(idx.x), i1 = rt_f2u(idx.y), i2 = rt_f2u(idx.z);
+  if (i0 >= n_verts) i0 = n_verts - 1;  // robust buffer access: clamp instead of faulting
+  if (i1 >= n_verts) i1 = n_verts - 1;
+  if (i2 >= n_verts) i2 = n_verts - 1;
+  rt3 v0 = xyz(pos[i0]), v1 = xyz(pos[i1]), v2 = xyz(pos[i2]);
+  rt3 e1 = v1 - v0, e2 = v2 - v0;
+  tri_geom[3 * i + 0] = make_float4(v0.x, v0.y, v0.z, 0.0f);
+  tri_geom[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+  tri_geom[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+}
+__global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __restrict__ inst_trav, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 c0 = inst[9 * i + 4], c1 = inst[9 * i + 5], c2 = inst[9 * i + 6], c3 = inst[9 * i + 7];
+  float4 meta = inst[9 * i + 8];
+  inst_trav[4 * i + 0] = make_float4(c0.x, c1.x, c2.x, c3.x);
+  inst_trav[4 * i + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+  inst_trav[4 * i + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+  inst_trav[4 * i + 3] = make_float4(meta.x, c0.w, c1.w, c2.w);
+}
+
+// ================================================================ primary visibility
+template <bool DETAIL>
+__global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame F, rt_scene_uniforms U) {
+  uint32_t x, y;
+  bool live = tile_pixel(U, x, y) && owns_row(F, y);
+  LaneCounters c = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    const uint32_t p_idx = y * U.width + x;
+    rt3 eye = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+    rt3 ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+    rt3 hor = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+    rt3 ver = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+    rt3 center = ll + hor * 0.5f + ver * 0.5f;
+    float focal_length = rt_length(center - eye);
+    const float z_near = 0.001f, z_far = 10000.0f;
+    float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
+    float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+    rt3 d = ll + u * hor + v * ver - eye;
+    c.primary = 1;
+    Hit hit = trace_closest<DETAIL>(S, U.blas_base_idx, eye, d, z_near / focal_length, z_far / focal_length, c);
+    if (hit.inst < 0) {
+      F.albedo[p_idx] = 0u;
+      F.normal_id[p_idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      F.depth[p_idx] = 1.0f;
+    } else {
+      InvRows m = load_inv_rows(S, (uint32_t)hit.inst);
+      Bary b = barycentrics(S, (uint32_t)hit.tri, mul_point(m, eye), mul_dir(m, d));
+      float4 idx = S.topo[5 * hit.tri], d0 = S.topo[5 * hit.tri + 1], d2 = S.topo[5 * hit.tri + 3];
+      uint32_t i0 = rt_f2u(idx.x), i1 = rt_f2u(idx.y), i2 = rt_f2u(idx.z);
+      rt3 wn0 = rt_normalize(normal_to_world(m, xyz(S.nrm[i0])));
+      rt3 wn1 = rt_normalize(normal_to_world(m, xyz(S.nrm[i1])));
+      rt3 wn2 = rt_normalize(normal_to_world(m, xyz(S.nrm[i2])));
+      rt3 n = rt_normalize(wn0 * b.w + wn1 * b.u + wn2 * b.v);
+      rt2 pn = pack_normal(n);
+      rt3 albedo = xyz(d0);
+      if (d2.x > -0.5f) {
+        float2 a0 = S.uv[i0], a1 = S.uv[i1], a2 = S.uv[i2];
+        rt2 tuv = rt2_make(a0.x, a0.y) * b.w + rt2_make(a1.x, a1.y) * b.u + rt2_make(a2.x, a2.y) * b.v;
+        albedo = albedo * sample_tex(S, tuv, rt_f2i32_sat(d2.x));
+      }
+      F.albedo[p_idx] = rt_unorm8(albedo.x) | (rt_unorm8(albedo.y) << 8) | (rt_unorm8(albedo.z) << 16) | (255u << 24);
+      F.normal_id[p_idx] = make_float4(pn.x, pn.y, rt_u2f((uint32_t)hit.tri), rt_u2f((uint32_t)hit.inst));
+      float z_view = hit.t * focal_length;
+      float z_clip = z_view * (z_far / (z_far - z_near)) - (z_far * z_near) / (z_far - z_near);
+      F.depth[p_idx] = z_clip / z_view;
+    }
+  }
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x);
+}
+
+// ======================================================================= path tracer
+// One sample: Raytracer.wgsl ray_color (:607-783).
+template <bool DETAIL>
+__device__ rt3 ray_color(const DevScene& S, const DevFrame& F, const rt_scene_uniforms& U, rt3 ro, rt3 rd,
+                         uint32_t& rng, uint32_t p_idx, LaneCounters& c) {
+  rt3 throughput = rt3_splat(1.0f);
+  rt3 radiance = rt3_splat(0.0f);
+  float prev_bsdf_pdf = 0.0f;
+  bool specular_bounce = true;
+
+  // depth 0 comes from the G-buffer
+  if (F.depth[p_idx] >= 1.0f) return radiance;
+  float4 g = F.normal_id[p_idx];
+  uint32_t tri = rt_f2u(g.z);
+  uint32_t inst = rt_f2u(g.w);
+  InvRows m = load_inv_rows(S, inst);
+  Bary b = barycentrics(S, tri, mul_point(m, ro), mul_dir(m, rd));
+  float hit_t = b.t;
+  float4 tidx = S.topo[5 * tri];
+  float2 uv0 = S.uv[rt_f2u(tidx.x)], uv1 = S.uv[rt_f2u(tidx.y)], uv2 = S.uv[rt_f2u(tidx.z)];
+  rt2 tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+  rt3 normal = unpack_normal(g.x, g.y);
+  uint32_t ga = F.albedo[p_idx];
+  rt3 albedo = rt3_make(rt_from_unorm8(ga & 255u), rt_from_unorm8((ga >> 8) & 255u), rt_from_unorm8((ga >> 16) & 255u));
+  rt3 world_geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+
+  for (uint32_t depth = 0u; depth < F.max_depth; depth++) {
+    if (DETAIL) c.shaded++;
+    float4 d0 = S.topo[5 * tri + 1], d1 = S.topo[5 * tri + 2], d2 = S.topo[5 * tri + 3], d3 = S.topo[5 * tri + 4];
+    uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
+    rt3 hit_p = ro + rd * hit_t;
+
+    normal = (rt_dot(rd, normal) < 0.0f) ? normal : -normal;
+    world_geom_n = (rt_dot(rd, world_geom_n) < 0.0f) ? world_geom_n : -world_geom_n;
+
+    float metallic = d1.x, roughness = d1.y;
+    if (d2.y > -0.5f) {
+      rt3 mr = sample_tex(S, tex_uv, rt_f2i32_sat(d2.y));
+      metallic *= mr.z;
+      roughness *= mr.y;
+    }
+    roughness = rt_max(roughness, 0.005f);
+    rt3 emissive = xyz(d3);
+    if (d2.w > -0.5f) emissive = emissive * sample_tex(S, tex_uv, rt_f2i32_sat(d2.w));
+    rt3 f0 = rt_mix3(rt3_splat(0.04f), albedo, metallic);
+
+    // emissive / light
+    if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
+      rt3 em_val = (mat_type == 3u) ? albedo : emissive;
+      if (specular_bounce) {
+        radiance = radiance + throughput * em_val;
+      } else {
+        radiance = radiance +
+                   throughput * em_val * power_heuristic(prev_bsdf_pdf, light_pdf(S, U.light_count, tri, inst, hit_t, rd));
+      }
+      if (mat_type == 3u) break;
+    }
+
+    // next-event estimation
+    if (mat_type != 2u) {
+      LightSample ls = sample_light(S, U.light_count, hit_p, rng);
+      if (ls.pdf > 0.0f) {
+        c.shadow++;
+        if (!trace_any<DETAIL>(S, U.blas_base_idx, hit_p + world_geom_n * 1e-4f, ls.dir, RT_T_MIN, ls.dist - 2e-4f, c)) {
+          rt3 bsdf_val = rt3_splat(0.0f);
+          float bsdf_pdf = 0.0f;
+          if (mat_type == 0u) {
+            bsdf_val = albedo / RT_PI;
+            bsdf_pdf = rt_max(rt_dot(normal, ls.dir), 0.0f) / RT_PI;
+          } else if (mat_type == 1u) {
+            bsdf_val = eval_ggx(normal, -rd, ls.dir, roughness, f0);
+            rt3 H = rt_normalize(-rd + ls.dir);
+            bsdf_pdf = (ggx_d(rt_dot(normal, H), roughness * roughness) * rt_max(rt_dot(normal, H), 0.0f)) /
+                       (4.0f * rt_max(rt_dot(-rd, H), 0.0f));
+          }
+          if (bsdf_pdf > 0.0f) {
+            radiance = radiance + throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                                      rt_max(rt_dot(normal, ls.dir), 0.0f) / ls.pdf;
+          }
+        }
+      }
+    }
+
+    Scatter sc;
+    if (mat_type == 0u) {
+      sc = sample_diffuse(normal, albedo, rng);
+    } else if (mat_type == 1u) {
+      sc = sample_ggx(normal, -rd, roughness, f0, rng);
+    } else {
+      sc = sample_dielectric(rd, normal, d1.z, albedo, rng);
+    }
+    if (mat_type != 2u && rt_dot(sc.dir, world_geom_n) <= 0.0f) {
+      sc.pdf = 0.0f;
+      sc.throughput = rt3_splat(0.0f);
+    }
+    if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) break;
+
+    throughput = throughput * sc.throughput;
+    rt3 offset_n = (rt_dot(sc.dir, world_geom_n) > 0.0f) ? world_geom_n : -world_geom_n;
+    ro = hit_p + offset_n * 1e-4f;
+    rd = sc.dir;
+    prev_bsdf_pdf = sc.pdf;
+    specular_bounce = sc.specular;
+
+    if (depth > 3u) {  // Russian roulette
+      float p = rt_max(throughput.x, rt_max(throughput.y, throughput.z));
+      if (rand_pcg(rng) > p) break;
+      throughput = throughput / p;
+    }
+
+    if (depth < F.max_depth - 1u) {
+      c.extension++;
+      Hit hit = trace_closest<DETAIL>(S, U.blas_base_idx, ro, rd, RT_T_MIN, RT_T_MAX, c);
+      if (hit.inst < 0) break;
+      hit_t = hit.t;
+      tri = (uint32_t)hit.tri;
+      inst = (uint32_t)hit.inst;
+      m = load_inv_rows(S, inst);
+      b = barycentrics(S, tri, mul_point(m, ro), mul_dir(m, rd));
+      tidx = S.topo[5 * tri];
+      uint32_t i0 = rt_f2u(tidx.x), i1 = rt_f2u(tidx.y), i2 = rt_f2u(tidx.z);
+      uv0 = S.uv[i0];
+      uv1 = S.uv[i1];
+      uv2 = S.uv[i2];
+      tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+      rt3 ln = rt_normalize(xyz(S.nrm[i0]) * b.w + xyz(S.nrm[i1]) * b.u + xyz(S.nrm[i2]) * b.v);
+      normal = rt_normalize(normal_to_world(m, ln));
+      float4 nd0 = S.topo[5 * tri + 1], nd2 = S.topo[5 * tri + 3];
+      albedo = xyz(nd0);
+      if (nd2.x > -0.5f) albedo = albedo * sample_tex(S, tex_uv, rt_f2i32_sat(nd2.x));
+      if (nd2.z > -0.5f) {
+        rt3 n_map = sample_tex(S, tex_uv, rt_f2i32_sat(nd2.z)) * 2.0f - rt3_splat(1.0f);
+        rt3 T = rt_normalize(b.e1);
+        rt3 B = rt_normalize(rt_cross(ln, T));
+        rt3 ln_mapped = rt_normalize(T * n_map.x + B * n_map.y + ln * n_map.z);
+        normal = rt_normalize(normal_to_world(m, ln_mapped));
+      }
+      world_geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+    }
+  }
+  return radiance;
+}
+
+// Raytracer.wgsl `main` (:791-819)
+template <bool DETAIL>
+__global__ __launch_bounds__(64) void k_pathtrace(DevScene S, DevFrame F, rt_scene_uniforms U) {
+  uint32_t x, y;
+  bool live = tile_pixel(U, x, y) && owns_row(F, y);
+  LaneCounters c = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    const uint32_t p_idx = y * U.width + x;
+    rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+    rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+    rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+    rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+    const float lens = U.camera.origin[3];
+    rt3 col = rt3_splat(0.0f);
+    for (uint32_t i = 0u; i < F.spp; i++) {
+      uint32_t rng = init_rng(p_idx, U.frame_count * F.spp + i);
+      rt3 off = rt3_splat(0.0f);
+      if (lens > 0.0f) {  // random_in_unit_disk (:201-205)
+        float r = rt_sqrt(rand_pcg(rng));
+        float theta = RT_TWO_PI * rand_pcg(rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+      rt3 d = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      col = col + ray_color<DETAIL>(S, F, U, cam_o + off, d, rng, p_idx, c);
+    }
+    col = col / (float)F.spp;
+    float4 acc = make_float4(col.x, col.y, col.z, 1.0f);
+    if (U.frame_count > 1u) {
+      float4 prev = F.accum[p_idx];
+      acc = make_float4(prev.x + col.x, prev.y + col.y, prev.z + col.z, prev.w + 1.0f);
+    }
+    F.accum[p_idx] = acc;
+  }
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x);
+}
+
+// ===================================================================== post process
+__device__ __forceinline__ rt3 pp_radiance(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :41-47
+  int x = cx < 0 ? 0 : (cx > (int)U.width - 1 ? (int)U.width - 1 : cx);
+  int y = cy < 0 ? 0 : (cy > (int)U.height - 1 ? (int)U.height - 1 : cy);
+  float4 a = P.accum[(size_t)y * U.width + (size_t)x];
+  if (a.w <= 0.0f) return rt3_splat(0.0f);
+  return rt3_make(a.x, a.y, a.z) / a.w;
+}
+__device__ rt3 pp_clean(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :49-68
+  rt3 center = pp_radiance(P, U, cx, cy);
+  rt3 max_nb = rt3_splat(-1e6f);
+  for (int y = -1; y <= 1; y++)
+    for (int x = -1; x <= 1; x++) {
+      if (x == 0 && y == 0) continue;
+      max_nb = rt_max3(max_nb, pp_radiance(P, U, cx + x, cy + y));
+    }
+  return rt_clamp3(center, rt3_splat(0.0f), max_nb * 3.0f + rt3_splat(0.1f));
+}
+__device__ rt3 pp_nearest(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :71-97
+  if (U.frame_count > 16u) return pp_clean(P, U, cx, cy);
+  float u = ((float)cx + 0.5f) / (float)U.width - U.average_jitter[0];
+  float v = ((float)cy + 0.5f) / (float)U.height - U.average_jitter[1];
+  float fx = u * (float)U.width - 0.5f, fy = v * (float)U.height - 0.5f;
+  float flx = rt_floor(fx), fly = rt_floor(fy);
+  int ix = rt_f2i32_sat(flx), iy = rt_f2i32_sat(fly);
+  float wx = fx - flx, wy = fy - fly;
+  rt3 c00 = pp_clean(P, U, ix, iy), c10 = pp_clean(P, U, ix + 1, iy);
+  rt3 c01 = pp_clean(P, U, ix, iy + 1), c11 = pp_clean(P, U, ix + 1, iy + 1);
+  return rt_mix3(rt_mix3(c00, c10, wx), rt_mix3(c01, c11, wx), wy);
+}
+__device__ __forceinline__ rt3 aces(rt3 color) {  // :36-39
+  const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+  rt3 num = color * (a * color + rt3_splat(b));
+  rt3 den = color * (c * color + rt3_splat(d)) + rt3_splat(e);
+  return rt_clamp3(num / den, rt3_splat(0.0f), rt3_splat(1.0f));
+}
+
+// Straight restatement: every get_radiance_nearest re-derives its footprint from the accumulation
+// buffer (served by L1/L2; the footprint of a 16x16 block is 22x22 pixels).
+__global__ __launch_bounds__(256) void k_postprocess(DevPost P, rt_scene_uniforms U) {
+  const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+  const uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
+  if (x >= U.width || y >= U.height) return;
+  const int ix = (int)x, iy = (int)y;
+  rt3 nb[9];
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) nb[(dy + 1) * 3 + (dx + 1)] = pp_nearest(P, U, ix + dx, iy + dy);
+  rt3 center_color = nb[4];
+
+  rt3 filtered_sum = rt3_splat(0.0f);
+  float total_weight = 0.0f;
+  rt3 m1 = rt3_splat(0.0f), m2 = rt3_splat(0.0f);
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) {
+      rt3 ncol = nb[(dy + 1) * 3 + (dx + 1)];
+      float w_s = rt_exp(-(float)(dx * dx + dy * dy) / 0.5f);  // 2 * SIGMA_S^2 = 0.5
+      rt3 cd = ncol - center_color;
+      float w_r = rt_exp(-rt_dot(cd, cd) / 0.2f);  // 2 * SIGMA_R * RADIUS^2 = f32(0.1) * 2
+      float w = w_s * w_r;
+      filtered_sum = filtered_sum + ncol * w;
+      total_weight += w;
+      m1 = m1 + ncol;
+      m2 = m2 + ncol * ncol;
+    }
+  rt3 denoised = filtered_sum / rt_max(total_weight, 1e-4f);
+
+  const size_t p_idx = (size_t)y * U.width + x;
+  ushort4 hp = P.history_in[p_idx];
+  rt3 hist = rt3_make(rt_f16_to_f32(hp.x), rt_f16_to_f32(hp.y), rt_f16_to_f32(hp.z));
+  rt3 mean = m1 / 9.0f;
+  rt3 var = rt_max3(m2 / 9.0f - mean * mean, rt3_splat(0.0f));
+  rt3 stddev = rt3_make(rt_sqrt(var.x), rt_sqrt(var.y), rt_sqrt(var.z));
+  float k = (U.frame_count > 16u) ? 60.0f : 1.0f;
+  rt3 clamped = rt_clamp3(hist, mean - stddev * k, mean + stddev * k);
+  float alpha = 1.0f / (float)U.frame_count;
+  if (U.frame_count == 1u) alpha = 0.1f;
+  alpha = rt_max(alpha, 0.0001f);
+  rt3 final_hdr = rt_mix3(clamped, denoised, alpha);
+  ushort4 ho;
+  ho.x = rt_f32_to_f16(final_hdr.x);
+  ho.y = rt_f32_to_f16(final_hdr.y);
+  ho.z = rt_f32_to_f16(final_hdr.z);
+  ho.w = rt_f32_to_f16(1.0f);
+  P.history_out[p_idx] = ho;
+
+  rt3 mapped = aces(final_hdr);
+  rt3 sharpened = mapped + aces(center_color - denoised) * 0.3f;
+  rt3 cl = rt_clamp3(sharpened, rt3_splat(0.0f), rt3_splat(1.0f));
+  const float inv_gamma = 0.4545454680919647216796875f;  // f32(1.0 / 2.2)
+  P.out_rgba8[p_idx] = rt_unorm8(rt_pow(cl.x, inv_gamma)) | (rt_unorm8(rt_pow(cl.y, inv_gamma)) << 8) |
+                       (rt_unorm8(rt_pow(cl.z, inv_gamma)) << 16) | (255u << 24);
+}
+
+}  // namespace rtk
+#endif

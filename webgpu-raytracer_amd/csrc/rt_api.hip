@@ -1,0 +1,652 @@
+// rt_api.hip — C ABI of include/mi355rt.h: resource management + kernel launches.
+//
+// Host-side restatement of the reference's ResourceManager / pass objects:
+//   buffer growth policy (1.5x, needsRebind)    src/renderer/ResourceManager.ts:209-228
+//   uniform packing + Halton jitter             src/renderer/ResourceManager.ts:348-447
+//   pass order compute(): raster -> raytrace    src/renderer/WebGPURenderer.ts:88-102
+//   present(): post pass, history ping-pong     src/renderer/WebGPURenderer.ts:104-129
+// There is no CPU fallback anywhere in this file: without a HIP device rt_create fails.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355rt.h"
+#include "kernels.hip.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t capacity = 0;  // bytes allocated
+  size_t size = 0;      // bytes in use
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // scene buffers (raw bridge layout)
+  DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures;
+  // derived buffers (device_scene.h)
+  DeviceBuffer tri_geom, inst_trav;
+  bool tris_dirty = true, inst_dirty = true;
+  uint32_t n_tris = 0, n_instances = 0, n_lights = 0, n_verts = 0, n_nodes = 0, tex_layers = 0;
+  std::vector<uint32_t> draw_commands_host;  // kept like ResourceManager.drawCommandsArray
+
+  // screen resources
+  uint32_t width = 0, height = 0;
+  DeviceBuffer accum, render_target, g_normal, g_depth, history[2], counters;
+  void* external_accum = nullptr;
+  int history_index = 0;
+
+  // uniforms + host state (ResourceManager fields)
+  rt_scene_uniforms uniforms;
+  float prev_camera[24];
+  double acc_jx = 0, acc_jy = 0, jx = 0, jy = 0, avg_jx = 0, avg_jy = 0;
+  uint32_t blas_offset = 0, vertex_count = 0, light_count = 0;
+  uint32_t total_frames = 0;  // WebGPURenderer.totalFrames
+  uint32_t max_depth = 10, spp = 1;
+  bool pipeline_built = false;
+  bool detailed_counters = false;
+  uint32_t stripe_rows = 0, stripe_rank = 0, stripe_count = 1;
+
+  // kernel timing
+  bool timing = false;
+  std::vector<EventPair> ev_pool;
+  size_t ev_used = 0;
+  std::vector<std::pair<size_t, int>> ev_tags;  // (pool index, 0 = primary, 1 = pathtrace)
+
+  rt_ctx() {
+    std::memset(&uniforms, 0, sizeof(uniforms));
+    std::memset(prev_camera, 0, sizeof(prev_camera));
+  }
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+  if (c) c->error = msg;
+  return code;
+}
+int hip_fail(rt_ctx* c, hipError_t e, const char* what) {
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  return fail(c, RT_ERR_HIP, buf);
+}
+#define HIP_TRY(ctx, expr)                                   \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return hip_fail((ctx), _e, #expr); \
+  } while (0)
+
+// ensureBuffer (ResourceManager.ts:209-228): keep when large enough, else reallocate at 1.5x.
+// Returns 1 when the buffer was (re)allocated, 0 when kept, <0 on error.
+int ensure_buffer(rt_ctx* c, DeviceBuffer& b, size_t bytes, bool grow_policy) {
+  b.size = bytes;
+  if (b.ptr && b.capacity >= bytes) return 0;
+  if (b.ptr) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+  }
+  size_t cap = bytes;
+  if (grow_policy) {
+    cap = (size_t)std::ceil((double)bytes * 1.5);
+    cap = (cap + 3) & ~(size_t)3;
+  }
+  if (cap < 16) cap = 16;
+  HIP_TRY(c, hipMalloc(&b.ptr, cap));
+  b.capacity = cap;
+  return 1;
+}
+void free_buffer(DeviceBuffer& b) {
+  if (b.ptr) (void)hipFree(b.ptr);
+  b = DeviceBuffer();
+}
+int upload(rt_ctx* c, DeviceBuffer& b, const void* src, size_t bytes) {
+  int r = ensure_buffer(c, b, bytes, true);
+  if (r < 0) return r;
+  if (bytes) {
+    // queue.writeBuffer semantics: the source may be reused right after return
+    HIP_TRY(c, hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return r;
+}
+
+double halton(uint32_t index, uint32_t base) {  // ResourceManager.ts:348-357 (JS doubles)
+  double f = 1, r = 0;
+  while (index > 0) {
+    f = f / (double)base;
+    r = r + f * (double)(index % base);
+    index = index / base;
+  }
+  return r;
+}
+// jitter + running average, shared by updateSceneUniforms (:366-371,385-394) and updateFrameUniforms (:408-424)
+void step_jitter(rt_ctx* c, uint32_t halton_source, uint32_t frame_count) {
+  c->jx = (halton((halton_source % 16u) + 1u, 2) - 0.5) / (double)c->width;
+  c->jy = (halton((halton_source % 16u) + 1u, 3) - 0.5) / (double)c->height;
+  if (frame_count == 1u) {
+    c->acc_jx = c->jx;
+    c->acc_jy = c->jy;
+  } else {
+    c->acc_jx += c->jx;
+    c->acc_jy += c->jy;
+  }
+  c->avg_jx = c->acc_jx / (double)frame_count;
+  c->avg_jy = c->acc_jy / (double)frame_count;
+}
+void write_mixed(rt_ctx* c, uint32_t frame_count) {  // the 48 bytes at offset 192
+  rt_scene_uniforms& u = c->uniforms;
+  u.frame_count = frame_count;
+  u.blas_base_idx = c->blas_offset;
+  u.vertex_count = c->vertex_count;
+  u.rand_seed = 0;  // Math.random() in the reference; no shader reads it
+  u.light_count = c->light_count;
+  u.width = c->width;
+  u.height = c->height;
+  u.pad = 0;
+  u.jitter[0] = (float)c->jx;
+  u.jitter[1] = (float)c->jy;
+  u.average_jitter[0] = (float)c->avg_jx;
+  u.average_jitter[1] = (float)c->avg_jy;
+}
+
+float4* accum_ptr(rt_ctx* c) { return (float4*)(c->external_accum ? c->external_accum : c->accum.ptr); }
+
+int prepare_scene(rt_ctx* c) {
+  if (c->tris_dirty && c->n_tris && c->n_verts) {
+    int r = ensure_buffer(c, c->tri_geom, (size_t)c->n_tris * 48, true);
+    if (r < 0) return r;
+    hipLaunchKernelGGL(rtk::k_prepare_tris, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream,
+                       (const float4*)c->topology.ptr, (const float4*)c->pos.ptr, (float4*)c->tri_geom.ptr,
+                       c->n_tris, c->n_verts);
+    HIP_TRY(c, hipGetLastError());
+    c->tris_dirty = false;
+  }
+  if (c->inst_dirty && c->n_instances) {
+    int r = ensure_buffer(c, c->inst_trav, (size_t)c->n_instances * 64, true);
+    if (r < 0) return r;
+    hipLaunchKernelGGL(rtk::k_prepare_instances, dim3((c->n_instances + 255) / 256), dim3(256), 0, c->stream,
+                       (const float4*)c->instances.ptr, (float4*)c->inst_trav.ptr, c->n_instances);
+    HIP_TRY(c, hipGetLastError());
+    c->inst_dirty = false;
+  }
+  return RT_OK;
+}
+
+// Host-side validation of everything the kernels index, so a malformed upload is refused
+// instead of faulting the GPU.
+bool scene_ready(const rt_ctx* c) {
+  return c->pipeline_built && c->width && c->height && c->n_tris && c->n_verts && c->n_instances && c->n_nodes &&
+         c->accum.ptr && c->lights.ptr;  // RaytracePass.updateBindGroup requires lightsBuffer (:38-46)
+}
+
+DevScene dev_scene(const rt_ctx* c) {
+  DevScene s;
+  s.nodes = (const float4*)c->nodes.ptr;
+  s.tri_geom = (const float4*)c->tri_geom.ptr;
+  s.inst_trav = (const float4*)c->inst_trav.ptr;
+  s.topo = (const float4*)c->topology.ptr;
+  s.pos = (const float4*)c->pos.ptr;
+  s.nrm = (const float4*)c->nrm.ptr;
+  s.uv = (const float2*)c->uv.ptr;
+  s.inst = (const float4*)c->instances.ptr;
+  s.lights = (const uint2*)c->lights.ptr;
+  s.tex = c->tex_layers ? (const uint8_t*)c->textures.ptr : nullptr;
+  s.tex_layers = c->tex_layers;
+  s.n_lights = c->n_lights;
+  return s;
+}
+
+EventPair* next_events(rt_ctx* c, int tag) {
+  if (!c->timing) return nullptr;
+  if (c->ev_used == c->ev_pool.size()) {
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(p);
+  }
+  c->ev_tags.emplace_back(c->ev_used, tag);
+  return &c->ev_pool[c->ev_used++];
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+rt_ctx* rt_create(int device_ordinal) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = "no HIP device available (the MI355X renderer has no CPU fallback)";
+    return nullptr;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) {
+    g_create_error = "device ordinal out of range";
+    return nullptr;
+  }
+  if (hipSetDevice(device_ordinal) != hipSuccess) {
+    g_create_error = "hipSetDevice failed";
+    return nullptr;
+  }
+  rt_ctx* c = new rt_ctx();
+  c->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_error = "hipStreamCreate failed";
+    delete c;
+    return nullptr;
+  }
+  c->stream = c->own_stream;
+  // counters: RT_COUNTER_SHARDS x 6 u64
+  if (hipMalloc(&c->counters.ptr, RT_COUNTER_SHARDS * 6 * sizeof(uint64_t)) != hipSuccess) {
+    g_create_error = "hipMalloc(counters) failed";
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+  }
+  c->counters.capacity = c->counters.size = RT_COUNTER_SHARDS * 6 * sizeof(uint64_t);
+  (void)hipMemsetAsync(c->counters.ptr, 0, c->counters.size, c->stream);
+  // lights buffer exists from the start with one dummy entry so that light_count == 0 scenes run
+  (void)hipMalloc(&c->lights.ptr, 16);
+  c->lights.capacity = 16;
+  (void)hipMemsetAsync(c->lights.ptr, 0, 16, c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  return c;
+}
+
+void rt_destroy(rt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
+                         &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->accum, &c->render_target,
+                         &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters};
+  for (DeviceBuffer* b : all) free_buffer(*b);
+  for (EventPair& p : c->ev_pool) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int rt_set_pipeline(rt_ctx* c, uint32_t max_depth, uint32_t spp) {
+  if (!c) return RT_ERR_INVALID;
+  if (spp == 0) return fail(c, RT_ERR_INVALID, "SPP must be >= 1");
+  c->max_depth = max_depth;
+  c->spp = spp;
+  c->pipeline_built = true;
+  return RT_OK;
+}
+
+int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
+  if (!c) return RT_ERR_INVALID;
+  if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
+    return fail(c, RT_ERR_INVALID, "invalid screen size");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)width * height;
+  // updateScreenSize destroys and recreates every screen resource (ResourceManager.ts:97-142);
+  // new WebGPU resources are zero-initialised.
+  struct {
+    DeviceBuffer* b;
+    size_t bytes;
+  } items[] = {{&c->accum, n * 16}, {&c->render_target, n * 4}, {&c->g_normal, n * 16},
+               {&c->g_depth, n * 4}, {&c->history[0], n * 8},   {&c->history[1], n * 8}};
+  for (auto& it : items) {
+    free_buffer(*it.b);
+    int r = ensure_buffer(c, *it.b, it.bytes, false);
+    if (r < 0) return r;
+    HIP_TRY(c, hipMemsetAsync(it.b->ptr, 0, it.bytes, c->stream));
+  }
+  c->width = width;
+  c->height = height;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_reset_accum(rt_ctx* c) {
+  if (!c) return RT_ERR_INVALID;
+  if (!c->accum.ptr) return RT_OK;  // `if (!this.accumulateBuffer) return;`
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(accum_ptr(c), 0, (size_t)c->width * c->height * 16, c->stream));
+  return RT_OK;
+}
+
+int rt_upload_textures(rt_ctx* c, const uint8_t* rgba, uint32_t layers) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (layers == 0) {
+    c->tex_layers = 0;
+    return RT_OK;
+  }
+  if (!rgba) return fail(c, RT_ERR_INVALID, "null texture data");
+  const size_t bytes = (size_t)layers * RT_TEX_SIZE * RT_TEX_SIZE * 4;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_buffer(c->textures);
+  int r = ensure_buffer(c, c->textures, bytes, false);
+  if (r < 0) return r;
+  HIP_TRY(c, hipMemcpyAsync(c->textures.ptr, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tex_layers = layers;
+  return RT_OK;
+}
+
+int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
+  if (!c) return RT_ERR_INVALID;
+  if (bytes && !data) return fail(c, RT_ERR_INVALID, "null data");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r;
+  switch (kind) {
+    case RT_KIND_TOPOLOGY:
+      if (bytes % sizeof(rt_topology)) return fail(c, RT_ERR_INVALID, "topology must be 80 bytes per triangle");
+      r = upload(c, c->topology, data, bytes);
+      if (r < 0) return r;
+      c->n_tris = (uint32_t)(bytes / sizeof(rt_topology));
+      c->tris_dirty = true;
+      return r;
+    case RT_KIND_INSTANCE:
+      if (bytes % sizeof(rt_instance)) return fail(c, RT_ERR_INVALID, "instances must be 144 bytes each");
+      r = upload(c, c->instances, data, bytes);
+      if (r < 0) return r;
+      c->n_instances = (uint32_t)(bytes / sizeof(rt_instance));
+      c->inst_dirty = true;
+      return r;
+    case RT_KIND_LIGHTS:
+      if (bytes % sizeof(rt_light_ref)) return fail(c, RT_ERR_INVALID, "lights must be 8 bytes each");
+      r = upload(c, c->lights, data, bytes);
+      if (r < 0) return r;
+      c->n_lights = (uint32_t)(bytes / sizeof(rt_light_ref));
+      return r;
+    case RT_KIND_DRAW_COMMANDS: {
+      // not on the 1.5x policy in the reference (ResourceManager.ts:264-278); kept on the host too
+      bool grew = !c->draw_commands.ptr || c->draw_commands.capacity < bytes;
+      if (grew) {
+        free_buffer(c->draw_commands);
+        r = ensure_buffer(c, c->draw_commands, bytes, false);
+        if (r < 0) return r;
+      }
+      if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(c->draw_commands.ptr, data, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+      }
+      c->draw_commands.size = bytes;
+      c->draw_commands_host.assign((const uint32_t*)data, (const uint32_t*)data + bytes / 4);
+      return grew ? RT_REALLOCATED : RT_OK;
+    }
+  }
+  return fail(c, RT_ERR_INVALID, "unknown buffer kind");
+}
+
+int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const float* uv2, uint32_t vertex_count) {
+  if (!c) return RT_ERR_INVALID;
+  if (vertex_count && (!pos4 || !nrm4 || !uv2)) return fail(c, RT_ERR_INVALID, "null geometry array");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // The reference packs the three arrays into one buffer at 256-byte aligned offsets because WebGPU
+  // binds sub-ranges (ResourceManager.ts:286-323); HIP needs no such aliasing, so they stay separate.
+  int r0 = upload(c, c->pos, pos4, (size_t)vertex_count * 16);
+  if (r0 < 0) return r0;
+  int r1 = upload(c, c->nrm, nrm4, (size_t)vertex_count * 16);
+  if (r1 < 0) return r1;
+  int r2 = upload(c, c->uv, uv2, (size_t)vertex_count * 8);
+  if (r2 < 0) return r2;
+  c->n_verts = vertex_count;
+  c->vertex_count = vertex_count;
+  c->tris_dirty = true;
+  return (r0 | r1 | r2) ? RT_REALLOCATED : RT_OK;
+}
+
+int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* blas, uint32_t n_blas) {
+  if (!c) return RT_ERR_INVALID;
+  if ((n_tlas && !tlas) || (n_blas && !blas)) return fail(c, RT_ERR_INVALID, "null BVH array");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t total = ((size_t)n_tlas + n_blas) * sizeof(rt_node);
+  int r = ensure_buffer(c, c->nodes, total, true);
+  if (r < 0) return r;
+  if (n_tlas)
+    HIP_TRY(c, hipMemcpyAsync(c->nodes.ptr, tlas, (size_t)n_tlas * 32, hipMemcpyHostToDevice, c->stream));
+  if (n_blas)
+    HIP_TRY(c, hipMemcpyAsync((char*)c->nodes.ptr + (size_t)n_tlas * 32, blas, (size_t)n_blas * 32,
+                              hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->blas_offset = n_tlas;  // this.blasOffset = tlas.length / 8
+  c->n_nodes = n_tlas + n_blas;
+  return r ? RT_REALLOCATED : RT_OK;
+}
+
+int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32_t light_count) {
+  if (!c || !camera) return RT_ERR_INVALID;
+  c->light_count = light_count;
+  step_jitter(c, frame_count, frame_count);
+  std::memcpy(&c->uniforms.camera, camera, 96);
+  std::memcpy(&c->uniforms.prev_camera, c->prev_camera, 96);
+  write_mixed(c, frame_count);
+  std::memcpy(c->prev_camera, camera, 96);
+  return RT_OK;
+}
+
+int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
+
+int rt_compute(rt_ctx* c, uint32_t frame_count) {
+  if (!c) return RT_ERR_INVALID;
+  c->total_frames++;
+  step_jitter(c, c->total_frames, frame_count);  // updateFrameUniforms(frameCount, totalFrames)
+  write_mixed(c, frame_count);
+  if (!scene_ready(c)) return RT_SKIPPED;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // Host-side shape checks before any kernel indexes these buffers.
+  if (c->uniforms.light_count > c->n_lights)
+    return fail(c, RT_ERR_INVALID, "light_count exceeds the uploaded lights buffer");
+  if (c->blas_offset > c->n_nodes) return fail(c, RT_ERR_INVALID, "blas_base_idx exceeds the node buffer");
+  int r = prepare_scene(c);
+  if (r < 0) return r;
+
+  DevScene S = dev_scene(c);
+  DevFrame F;
+  F.accum = accum_ptr(c);
+  F.albedo = (uint32_t*)c->render_target.ptr;
+  F.normal_id = (float4*)c->g_normal.ptr;
+  F.depth = (float*)c->g_depth.ptr;
+  F.counters = (uint64_t*)c->counters.ptr;
+  F.max_depth = c->max_depth;
+  F.spp = c->spp;
+  F.stripe_rows = c->stripe_rows;
+  F.stripe_rank = c->stripe_rank;
+  F.stripe_count = c->stripe_count;
+
+  const uint32_t tiles = ((c->width + 7) / 8) * ((c->height + 7) / 8);
+  // 1. primary visibility (the reference clears + rasterises the G-buffer every compute())
+  EventPair* ev = next_events(c, 0);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+  if (c->detailed_counters)
+    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+  else
+    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  // 2. path trace
+  ev = next_events(c, 1);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+  if (c->detailed_counters)
+    hipLaunchKernelGGL(rtk::k_pathtrace<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+  else
+    hipLaunchKernelGGL(rtk::k_pathtrace<false>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_present(rt_ctx* c) {
+  if (!c) return RT_ERR_INVALID;
+  if (!c->width || !c->render_target.ptr || !c->accum.ptr) return RT_SKIPPED;  // PostProcessPass.ts:32-38
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevPost P;
+  P.accum = accum_ptr(c);
+  P.history_in = (const ushort4*)c->history[1 - c->history_index].ptr;  // previous frame (read)
+  P.history_out = (ushort4*)c->history[c->history_index].ptr;           // current frame (write)
+  P.out_rgba8 = (uint32_t*)c->render_target.ptr;
+  dim3 grid((c->width + 15) / 16, (c->height + 15) / 16);
+  hipLaunchKernelGGL(rtk::k_postprocess, grid, dim3(256), 0, c->stream, P, c->uniforms);
+  HIP_TRY(c, hipGetLastError());
+  c->history_index = 1 - c->history_index;  // swap history index for TAA
+  return RT_OK;
+}
+
+int rt_capture(rt_ctx* c, uint8_t* out_rgba, size_t cap) {
+  if (!c || !out_rgba) return RT_ERR_INVALID;
+  if (!c->render_target.ptr) return fail(c, RT_ERR_NOT_READY, "No render target");  // WebGPUContext.ts:43
+  const size_t bytes = (size_t)c->width * c->height * 4;
+  if (cap < bytes) return fail(c, RT_ERR_INVALID, "capture buffer too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out_rgba, c->render_target.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_sync(rt_ctx* c) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------- additions
+int rt_read_accum(rt_ctx* c, float* out, size_t cap) {
+  if (!c || !out) return RT_ERR_INVALID;
+  const size_t bytes = (size_t)c->width * c->height * 16;
+  if (!c->accum.ptr) return fail(c, RT_ERR_NOT_READY, "no accumulation buffer");
+  if (cap < bytes) return fail(c, RT_ERR_INVALID, "buffer too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out, accum_ptr(c), bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+int rt_write_accum(rt_ctx* c, const float* in, size_t bytes) {
+  if (!c || !in) return RT_ERR_INVALID;
+  if (!c->accum.ptr || bytes != (size_t)c->width * c->height * 16)
+    return fail(c, RT_ERR_INVALID, "accumulation size mismatch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(accum_ptr(c), in, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+int rt_read_gbuffer(rt_ctx* c, uint8_t* albedo, float* normal_id, float* depth) {
+  if (!c) return RT_ERR_INVALID;
+  if (!c->render_target.ptr) return fail(c, RT_ERR_NOT_READY, "no G-buffer");
+  const size_t n = (size_t)c->width * c->height;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (albedo) HIP_TRY(c, hipMemcpyAsync(albedo, c->render_target.ptr, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (normal_id) HIP_TRY(c, hipMemcpyAsync(normal_id, c->g_normal.ptr, n * 16, hipMemcpyDeviceToHost, c->stream));
+  if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->g_depth.ptr, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+int rt_read_history(rt_ctx* c, uint16_t* out, size_t cap) {
+  if (!c || !out) return RT_ERR_INVALID;
+  const size_t bytes = (size_t)c->width * c->height * 8;
+  if (!c->history[0].ptr) return fail(c, RT_ERR_NOT_READY, "no history");
+  if (cap < bytes) return fail(c, RT_ERR_INVALID, "buffer too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out, c->history[1 - c->history_index].ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+int rt_read_uniforms(rt_ctx* c, void* out256) {
+  if (!c || !out256) return RT_ERR_INVALID;
+  std::memcpy(out256, &c->uniforms, 256);
+  return RT_OK;
+}
+int rt_get_counters(rt_ctx* c, rt_counters* out) {
+  if (!c || !out) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<uint64_t> host((size_t)RT_COUNTER_SHARDS * 6);
+  HIP_TRY(c, hipMemcpyAsync(host.data(), c->counters.ptr, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t sum[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t s = 0; s < RT_COUNTER_SHARDS; s++)
+    for (int k = 0; k < 6; k++) sum[k] += host[s * 6 + k];
+  out->primary_rays = sum[0];
+  out->extension_rays = sum[1];
+  out->shadow_rays = sum[2];
+  out->nodes_visited = sum[3];
+  out->tris_tested = sum[4];
+  out->shaded_hits = sum[5];
+  return RT_OK;
+}
+int rt_reset_counters(rt_ctx* c) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->counters.ptr, 0, c->counters.size, c->stream));
+  return RT_OK;
+}
+int rt_set_counting(rt_ctx* c, int detailed) {
+  if (!c) return RT_ERR_INVALID;
+  c->detailed_counters = detailed != 0;
+  return RT_OK;
+}
+int rt_set_stripes(rt_ctx* c, uint32_t stripe_rows, uint32_t rank, uint32_t count) {
+  if (!c) return RT_ERR_INVALID;
+  if (count > 1 && (stripe_rows == 0 || rank >= count)) return fail(c, RT_ERR_INVALID, "invalid stripe spec");
+  c->stripe_rows = stripe_rows;
+  c->stripe_rank = rank;
+  c->stripe_count = count ? count : 1;
+  return RT_OK;
+}
+void* rt_accum_device_ptr(rt_ctx* c) { return c ? (void*)accum_ptr(c) : nullptr; }
+int rt_set_stream(rt_ctx* c, void* hip_stream) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return RT_OK;
+}
+int rt_set_kernel_timing(rt_ctx* c, int enabled) {
+  if (!c) return RT_ERR_INVALID;
+  c->timing = enabled != 0;
+  return RT_OK;
+}
+int rt_kernel_time_ms(rt_ctx* c, double* avg_pt, double* avg_pv, uint32_t* launches) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double sum[2] = {0, 0};
+  uint32_t cnt[2] = {0, 0};
+  for (auto& t : c->ev_tags) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_pool[t.first].a, c->ev_pool[t.first].b) == hipSuccess) {
+      sum[t.second] += ms;
+      cnt[t.second]++;
+    }
+  }
+  if (avg_pv) *avg_pv = cnt[0] ? sum[0] / cnt[0] : 0.0;
+  if (avg_pt) *avg_pt = cnt[1] ? sum[1] / cnt[1] : 0.0;
+  if (launches) *launches = cnt[1];
+  c->ev_tags.clear();
+  c->ev_used = 0;
+  return RT_OK;
+}
+
+}  // extern "C"
