@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json on MI355X.
+
+Metric   : Mrays/s (primary + secondary) at 1920x1080, SPP = 64, depth = 8 (Cornell box).
+Step     : one full image = resetAccumulation + 64 x compute(frame_count = 1..64) with shader
+           SPP = 1 (the canonical decomposition) + one present().
+Rays     : primary-visibility casts + extension rays + shadow rays actually traced, from the
+           device counters (deterministic; cross-checked against the oracle in tests/).
+N > 1    : the image is split into interleaved 16-row stripes across ranks (strong scaling of one
+           image), one RCCL sum-reduce of the float4 accumulation buffer to rank 0 per image.
+Extra    : "roofline" for the dominant kernel (k_pathtrace; HIP events inside the C library, on the
+           stream the kernel runs on) and "cpu_baseline" (the CPU oracle timed on a bounded
+           1/4 row-interleaved sample of the same workload, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WIDTH, HEIGHT, SPP_TOTAL, DEPTH = 1920, 1080, 64, 8
+SCENE = "cornell"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pkg, bridge, frames):
+    """Time the CPU oracle (C++ scalar restatement, all host threads) on rows
+    {y : (y // 8) % 16 == 0} of the same 1080p frames: a 1/16 row-interleaved sample."""
+    import oracle_lib
+    cpu = oracle_lib.OracleRenderer()
+    cores = oracle_lib.lib().oracle_hardware_threads()
+    cpu.buildPipeline(DEPTH, 1)
+    pkg.upload_scene(cpu, bridge, WIDTH, HEIGHT)
+    cpu.setStripes(8, 0, 4)
+    cpu.resetCounters()
+    t0 = time.perf_counter()
+    for f in frames:
+        cpu.compute(f)
+    dt = time.perf_counter() - t0
+    c = cpu.getCounters()
+    rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(cores), "kind": "port",
+            "sample": "rows (y//8)%%4==0 (1/4 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s"
+                      % (WIDTH * HEIGHT // 4, len(frames), DEPTH, rays / 1e6, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import webgpu_raytracer_amd as pkg
+    from webgpu_raytracer_amd import distributed as rtdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP renderer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    bridge = pkg.WorldBridge()
+    bridge.loadScene(SCENE)
+    r = pkg.WebGPURenderer(local_rank)
+    r.buildPipeline(DEPTH, 1)
+    pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
+    accum_t = rtdist.bind_torch_accum(r, device)
+    shard = rtdist.ShardedImage(r, rank, world, device_tensor=accum_t if world > 1 else None)
+    frames = list(range(1, SPP_TOTAL + 1))
+
+    def step():
+        r.resetAccumulation()
+        shard.render(frames)
+        shard.gather(present=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.resetCounters()
+    r.setKernelTiming(True)
+    r.kernelTimeMs()  # drop anything recorded so far
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ktime = r.kernelTimeMs()
+    r.setKernelTiming(False)
+
+    counts = r.getCounters()
+    rays_local = counts["primary_rays"] + counts["extension_rays"] + counts["shadow_rays"]
+    stats = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = stats[1:].clone()
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_total = float(tmax.item()), float(rsum.item())
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        # one extra untimed image with the detailed-counter kernel variant: per-launch algorithmic bytes
+        # of the dominant kernel (counts are deterministic, so they equal the timed launches')
+        r.setCounting(True)
+        r.resetCounters()
+        shard.render(frames)
+        r.sync()
+        kc = r.getKernelCounters(1)
+        r.setCounting(False)
+        n_launch = len(frames)
+        owned_px = int(shard.owned_rows(HEIGHT).sum()) * WIDTH
+        alg_bytes = (32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"] + 344.0 * kc["shaded_hits"]) / n_launch \
+            + (32.0 + 24.0) * owned_px  # accumulation read+write, G-buffer read
+        achieved = alg_bytes / (ktime["pathtrace_ms"] * 1e-3) / 1e9 if ktime["pathtrace_ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_pathtrace_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 1920x1080 SPP=64 depth=8",
+            "value": round(rays_total / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cornell box 1920x1080, 64 spp as 1 spp x 64 compute() dispatches, depth 8, "
+                                   "live-loop frame_count 1..64, one present() per image",
+                       "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
+                       "parallelism": "16-row stripes x %d ranks + 1 RCCL reduce/image" % world if world > 1 else "1 GPU",
+                       "rays_per_image": int(rays_total / args.steps)},
+            "roofline": {"bound": "hbm", "kernel": "k_pathtrace", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "avg_launch_ms": round(ktime["pathtrace_ms"], 4),
+                         "avg_primary_ms": round(ktime["primary_ms"], 4), "launches": ktime["launches"],
+                         "alg_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, bridge, frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,7 +112,9 @@ int rt_write_accum(rt_ctx* ctx, const float* in_rgba32f, size_t bytes);
 int rt_read_gbuffer(rt_ctx* ctx, uint8_t* albedo_rgba8, float* normal_id_rgba32f, float* depth_f32);
 int rt_read_history(rt_ctx* ctx, uint16_t* out_rgba16f, size_t cap_bytes); /* last written history texture */
 int rt_read_uniforms(rt_ctx* ctx, void* out256);                            /* the 256-byte scene uniform block */
-int rt_get_counters(rt_ctx* ctx, rt_counters* out);                         /* blocking */
+int rt_get_counters(rt_ctx* ctx, rt_counters* out);                         /* blocking; both kernels */
+/* counters of one kernel only: 0 = primary-visibility kernel, 1 = path-trace kernel */
+int rt_get_kernel_counters(rt_ctx* ctx, int kernel, rt_counters* out);
 int rt_reset_counters(rt_ctx* ctx);
 /* count nodes/tris/shaded hits too (slower kernel variant); rays are always counted */
 int rt_set_counting(rt_ctx* ctx, int detailed);
@@ -122,6 +124,10 @@ int rt_set_stripes(rt_ctx* ctx, uint32_t stripe_rows, uint32_t rank, uint32_t co
 /* Raw device pointer of the float4 accumulation buffer (width*height*16 bytes) so the caller
  * can hand it to a collective (RCCL) without a host round trip. */
 void* rt_accum_device_ptr(rt_ctx* ctx);
+/* Use caller-owned device memory (width*height*16 bytes, same device) as the accumulation buffer,
+ * e.g. a tensor the caller will hand to RCCL; NULL returns to the context's own buffer.
+ * Call after rt_resize; the binding does not survive a later rt_resize of a different size. */
+int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
 /* Run every subsequent enqueue on a caller-provided hipStream_t (NULL = context's own stream). */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Average duration in ms of the path-trace kernel over the launches since the last call

@@ -259,14 +259,14 @@ rt_ctx* rt_create(int device_ordinal) {
     return nullptr;
   }
   c->stream = c->own_stream;
-  // counters: RT_COUNTER_SHARDS x 6 u64
-  if (hipMalloc(&c->counters.ptr, RT_COUNTER_SHARDS * 6 * sizeof(uint64_t)) != hipSuccess) {
+  // counters: 2 banks (primary kernel, path-trace kernel) x RT_COUNTER_SHARDS x 6 u64
+  if (hipMalloc(&c->counters.ptr, 2 * RT_COUNTER_SHARDS * 6 * sizeof(uint64_t)) != hipSuccess) {
     g_create_error = "hipMalloc(counters) failed";
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return nullptr;
   }
-  c->counters.capacity = c->counters.size = RT_COUNTER_SHARDS * 6 * sizeof(uint64_t);
+  c->counters.capacity = c->counters.size = 2 * RT_COUNTER_SHARDS * 6 * sizeof(uint64_t);
   (void)hipMemsetAsync(c->counters.ptr, 0, c->counters.size, c->stream);
   // lights buffer exists from the start with one dummy entry so that light_count == 0 scenes run
   (void)hipMalloc(&c->lights.ptr, 16);
@@ -325,6 +325,7 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   }
   c->width = width;
   c->height = height;
+  c->external_accum = nullptr;  // a bound accumulation buffer belongs to the old size
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RT_OK;
 }
@@ -478,14 +479,16 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
   F.stripe_rank = c->stripe_rank;
   F.stripe_count = c->stripe_count;
 
+  DevFrame Fp = F;  // the primary kernel counts into bank 0, the path tracer into bank 1
+  F.counters = (uint64_t*)c->counters.ptr + (size_t)RT_COUNTER_SHARDS * 6;
   const uint32_t tiles = ((c->width + 7) / 8) * ((c->height + 7) / 8);
   // 1. primary visibility (the reference clears + rasterises the G-buffer every compute())
   EventPair* ev = next_events(c, 0);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   if (c->detailed_counters)
-    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles), dim3(64), 0, c->stream, S, Fp, c->uniforms);
   else
-    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles), dim3(64), 0, c->stream, S, Fp, c->uniforms);
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
   // 2. path trace
   ev = next_events(c, 1);
@@ -579,15 +582,15 @@ int rt_read_uniforms(rt_ctx* c, void* out256) {
   std::memcpy(out256, &c->uniforms, 256);
   return RT_OK;
 }
-int rt_get_counters(rt_ctx* c, rt_counters* out) {
-  if (!c || !out) return RT_ERR_INVALID;
+static int read_counters(rt_ctx* c, int bank_lo, int bank_hi, rt_counters* out) {
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<uint64_t> host((size_t)RT_COUNTER_SHARDS * 6);
+  std::vector<uint64_t> host((size_t)2 * RT_COUNTER_SHARDS * 6);
   HIP_TRY(c, hipMemcpyAsync(host.data(), c->counters.ptr, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   uint64_t sum[6] = {0, 0, 0, 0, 0, 0};
-  for (size_t s = 0; s < RT_COUNTER_SHARDS; s++)
-    for (int k = 0; k < 6; k++) sum[k] += host[s * 6 + k];
+  for (int b = bank_lo; b <= bank_hi; b++)
+    for (size_t s = 0; s < RT_COUNTER_SHARDS; s++)
+      for (int k = 0; k < 6; k++) sum[k] += host[((size_t)b * RT_COUNTER_SHARDS + s) * 6 + k];
   out->primary_rays = sum[0];
   out->extension_rays = sum[1];
   out->shadow_rays = sum[2];
@@ -595,6 +598,14 @@ int rt_get_counters(rt_ctx* c, rt_counters* out) {
   out->tris_tested = sum[4];
   out->shaded_hits = sum[5];
   return RT_OK;
+}
+int rt_get_counters(rt_ctx* c, rt_counters* out) {
+  if (!c || !out) return RT_ERR_INVALID;
+  return read_counters(c, 0, 1, out);
+}
+int rt_get_kernel_counters(rt_ctx* c, int kernel, rt_counters* out) {
+  if (!c || !out || kernel < 0 || kernel > 1) return RT_ERR_INVALID;
+  return read_counters(c, kernel, kernel, out);
 }
 int rt_reset_counters(rt_ctx* c) {
   if (!c) return RT_ERR_INVALID;
@@ -616,6 +627,13 @@ int rt_set_stripes(rt_ctx* c, uint32_t stripe_rows, uint32_t rank, uint32_t coun
   return RT_OK;
 }
 void* rt_accum_device_ptr(rt_ctx* c) { return c ? (void*)accum_ptr(c) : nullptr; }
+int rt_bind_accum(rt_ctx* c, void* device_ptr) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->external_accum = device_ptr;
+  return RT_OK;
+}
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
   if (!c) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));

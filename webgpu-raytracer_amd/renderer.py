@@ -47,6 +47,7 @@ def load_library(path=None):
         "rt_read_accum": (i32, [vp, vp, ctypes.c_size_t]), "rt_write_accum": (i32, [vp, vp, ctypes.c_size_t]),
         "rt_read_gbuffer": (i32, [vp, vp, vp, vp]), "rt_read_history": (i32, [vp, vp, ctypes.c_size_t]),
         "rt_read_uniforms": (i32, [vp, vp]), "rt_get_counters": (i32, [vp, vp]),
+        "rt_get_kernel_counters": (i32, [vp, i32, vp]), "rt_bind_accum": (i32, [vp, vp]),
         "rt_reset_counters": (i32, [vp]), "rt_set_counting": (i32, [vp, i32]),
         "rt_set_stripes": (i32, [vp, u32, u32, u32]), "rt_accum_device_ptr": (vp, [vp]),
         "rt_set_stream": (i32, [vp, vp]),
@@ -67,6 +68,7 @@ EXPORTED_SYMBOLS = (
     "rt_create rt_destroy rt_last_error rt_set_pipeline rt_resize rt_reset_accum rt_upload_textures rt_upload "
     "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
+    "rt_get_kernel_counters rt_bind_accum "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count").split()
 
@@ -201,6 +203,15 @@ class WebGPURenderer:
         out = np.zeros(6, dtype=np.uint64)
         self._check(self.L.rt_get_counters(self.ctx, _ptr(out)), "getCounters")
         return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+    def getKernelCounters(self, kernel):
+        """kernel: 0 = primary visibility, 1 = path trace"""
+        out = np.zeros(6, dtype=np.uint64)
+        self._check(self.L.rt_get_kernel_counters(self.ctx, int(kernel), _ptr(out)), "getKernelCounters")
+        return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+    def bindAccum(self, device_ptr):
+        self._check(self.L.rt_bind_accum(self.ctx, ctypes.c_void_p(device_ptr)), "bindAccum")
 
     def resetCounters(self):
         self._check(self.L.rt_reset_counters(self.ctx), "resetCounters")
