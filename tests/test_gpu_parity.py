@@ -60,6 +60,21 @@ def test_present_parity_live_loop(W, oracle_lib, gpu_renderer, scene, w, h, dept
     pu.assert_parity(gpu_renderer, cpu, check_output=True)
 
 
+@pytest.mark.parametrize("scene,w,h,depth,spp,frames", [
+    ("cornell", 72, 40, 8, 2, (1, 2)),
+    ("instanced1000", 64, 36, 8, 1, (1,)),
+    ("mixed", 64, 48, 10, 1, (1, 2)),
+])
+def test_megakernel_variant_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, spp, frames):
+    """The one-pixel-per-lane kernel form (kept for A/B timing) must agree with the oracle too."""
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    gpu_renderer.setKernelVariant(0)
+    pu.drive(gpu_renderer, W, b, w, h, depth, spp, frames, present=False)
+    pu.drive(cpu, W, b, w, h, depth, spp, frames, present=False)
+    pu.assert_parity(gpu_renderer, cpu, check_output=False)
+
+
 def test_recorder_semantics_frame_count_from_zero(W, oracle_lib, gpu_renderer):
     """VideoRecorder passes frame_count = 0, 1, 2, ... (VideoRecorder.ts:278-280): frames 0 and 1 both
     overwrite, and the post pass at frame 0 has alpha = 1/0."""

@@ -816,6 +816,468 @@ __global__ __launch_bounds__(64) void k_pathtrace(DevScene S, DevFrame F, rt_sce
   flush_counters<DETAIL>(c, F.counters, blockIdx.x);
 }
 
+// ============================================================ path tracer, persistent form
+// k_pathtrace_persistent: the production path-trace kernel.
+//
+//  * persistent waves: the grid is sized to the resident wave count; each wave pulls 8x8 pixel
+//    tiles from a global ticket counter until the image is exhausted (one ray per lane);
+//  * path regeneration: a lane whose path ended (light hit, miss, absorbed, Russian roulette,
+//    depth limit) takes the next pixel of its wave's current tile, found with a ballot/mbcnt prefix
+//    over the idle mask, so the 64 lanes stay busy instead of waiting for the longest path;
+//  * per trip every live lane executes exactly one bounce: shade -> (NEE shadow ray) -> scatter ->
+//    (extension ray), so the wave runs the two traversals and the shading code converged;
+//  * traversal data (nodes, triangle records, instance records) is staged once per workgroup in LDS
+//    when it fits (LDS = true); larger scenes read the same records through L1/L2;
+//  * TLAS and BLAS are walked by ONE loop with an in-instance flag, so lanes in different
+//    instances / levels share the node fetch + slab test.
+// Per-path arithmetic and RNG draw order are exactly those of ray_color above (and of the oracle);
+// only the scheduling differs, which cannot change any pixel because paths are independent.
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct TravMem {  // pointers may be LDS or global; the template flag keeps the two code paths apart
+  const f4* nodes;
+  const f4* tri_geom;
+  const f4* inst_trav;
+};
+
+__device__ __forceinline__ bool hit_box4(f4 lo, f4 hi, const LocalRay& r, float t_min, float t_max) {
+  float t1x = lo.x * r.inv_d.x - r.o_inv_d.x, t2x = hi.x * r.inv_d.x - r.o_inv_d.x;
+  float t1y = lo.y * r.inv_d.y - r.o_inv_d.y, t2y = hi.y * r.inv_d.y - r.o_inv_d.y;
+  float t1z = lo.z * r.inv_d.z - r.o_inv_d.z, t2z = hi.z * r.inv_d.z - r.o_inv_d.z;
+  float nx = rt_min(t1x, t2x), ny = rt_min(t1y, t2y), nz = rt_min(t1z, t2z);
+  float fx = rt_max(t1x, t2x), fy = rt_max(t1y, t2y), fz = rt_max(t1z, t2z);
+  float tm_near = rt_max(t_min, rt_max(nx, rt_max(ny, nz)));
+  float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
+  return tm_near <= tm_far;
+}
+__device__ __forceinline__ float hit_tri4(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max) {
+  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
+  rt3 h = rt_cross(r.d, e2);
+  float a = rt_dot(e1, h);
+  if (rt_abs(a) < 1e-6f) return -1.0f;
+  float f = 1.0f / a;
+  rt3 s = r.o - v0;
+  float u = f * rt_dot(s, h);
+  if (u < 0.0f || u > 1.0f) return -1.0f;
+  rt3 q = rt_cross(s, e1);
+  float v = f * rt_dot(r.d, q);
+  if (v < 0.0f || u + v > 1.0f) return -1.0f;
+  float t = f * rt_dot(e2, q);
+  return (t > t_min && t < t_max) ? t : -1.0f;
+}
+__device__ __forceinline__ LocalRay to_instance(const TravMem& M, uint32_t inst, rt3 o, rt3 d, uint32_t& blas_off) {
+  f4 r0 = M.inst_trav[4 * inst + 0], r1 = M.inst_trav[4 * inst + 1], r2 = M.inst_trav[4 * inst + 2];
+  blas_off = rt_f2u(M.inst_trav[4 * inst + 3].x);
+  rt3 lo = rt3_make(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w * 1.0f, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w * 1.0f,
+                    r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w * 1.0f);
+  rt3 ld = rt3_make(r0.x * d.x + r0.y * d.y + r0.z * d.z + r0.w * 0.0f, r1.x * d.x + r1.y * d.y + r1.z * d.z + r1.w * 0.0f,
+                    r2.x * d.x + r2.y * d.y + r2.z * d.z + r2.w * 0.0f);
+  return make_ray(lo, ld);
+}
+
+// One loop over TLAS and BLAS nodes. ANY = shadow ray (first hit ends), else closest hit.
+// `active` lanes trace; the others skip the loop (their exec bit is simply off).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void traverse(const TravMem& M, uint32_t blas_base, bool active, rt3 o, rt3 d, float t_min,
+                                         float t_max, float& out_t, int32_t& out_tri, int32_t& out_inst, bool& out_any,
+                                         uint32_t& n_nodes, uint32_t& n_tris) {
+  float closest = t_max;
+  int32_t best_tri = -1, best_inst = -1;
+  bool any = false;
+  if (active && blas_base != 0u) {
+    LocalRay r = make_ray(o, d);
+    const uint32_t tlas_end = rt_f2u(M.nodes[0].w);
+    uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
+    uint32_t cur_inst = 0u;
+    bool in_blas = false;
+    for (;;) {
+      if (curr >= end) {
+        if (!in_blas) break;
+        in_blas = false;  // instance finished: back to the world-space ray and the TLAS cursor
+        r = make_ray(o, d);
+        curr = tlas_next;
+        end = tlas_end;
+        base = 0u;
+        continue;
+      }
+      f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+      if (COUNT) n_nodes++;
+      uint32_t next = base + rt_f2u(lo.w);
+      if (hit_box4(lo, hi, r, t_min, closest)) {
+        const uint32_t data = rt_f2u(hi.w);
+        if (data == 0u) {
+          next = curr + 1u;
+        } else if (!in_blas) {
+          cur_inst = data >> 3;
+          uint32_t off;
+          r = to_instance(M, cur_inst, o, d, off);
+          tlas_next = next;
+          base = blas_base + off;
+          end = base + rt_f2u(M.nodes[2 * base].w);
+          next = base;
+          in_blas = true;
+        } else {
+          const uint32_t first = data >> 3, count = data & 7u;
+          for (uint32_t i = 0; i < count; i++) {
+            const uint32_t tri = first + i;
+            if (COUNT) n_tris++;
+            float t = hit_tri4(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], r, t_min, closest);
+            if (t > 0.0f) {
+              if (ANY) {
+                any = true;
+                break;
+              }
+              closest = t;
+              best_tri = (int32_t)tri;
+              best_inst = (int32_t)cur_inst;
+            }
+          }
+          if (ANY && any) break;
+        }
+      }
+      curr = next;
+    }
+  }
+  out_t = closest;
+  out_tri = best_tri;
+  out_inst = best_inst;
+  out_any = any;
+}
+
+struct PathState {
+  uint32_t pixel, rng, depth, sample;
+  rt3 ro, rd, throughput, radiance, col;
+  float prev_pdf;
+  bool specular;
+  // current surface
+  float hit_t;
+  uint32_t tri, inst;
+  rt3 normal, geom_n, albedo;
+  rt2 tex_uv;
+};
+
+// surface frame of the hit (tri, inst) for the ray (ro, rd): Raytracer.wgsl:738-779
+__device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, bool from_gbuffer, float gx, float gy,
+                                              uint32_t galbedo) {
+  InvRows m = load_inv_rows(S, p.inst);
+  Bary b = barycentrics(S, p.tri, mul_point(m, p.ro), mul_dir(m, p.rd));
+  float4 tidx = S.topo[5 * p.tri];
+  uint32_t i0 = rt_f2u(tidx.x), i1 = rt_f2u(tidx.y), i2 = rt_f2u(tidx.z);
+  float2 uv0 = S.uv[i0], uv1 = S.uv[i1], uv2 = S.uv[i2];
+  p.tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+  if (from_gbuffer) {
+    p.hit_t = b.t;
+    p.normal = unpack_normal(gx, gy);
+    p.albedo = rt3_make(rt_from_unorm8(galbedo & 255u), rt_from_unorm8((galbedo >> 8) & 255u),
+                        rt_from_unorm8((galbedo >> 16) & 255u));
+  } else {
+    rt3 ln = rt_normalize(xyz(S.nrm[i0]) * b.w + xyz(S.nrm[i1]) * b.u + xyz(S.nrm[i2]) * b.v);
+    p.normal = rt_normalize(normal_to_world(m, ln));
+    float4 nd0 = S.topo[5 * p.tri + 1], nd2 = S.topo[5 * p.tri + 3];
+    p.albedo = xyz(nd0);
+    if (nd2.x > -0.5f) p.albedo = p.albedo * sample_tex(S, p.tex_uv, rt_f2i32_sat(nd2.x));
+    if (nd2.z > -0.5f) {
+      rt3 n_map = sample_tex(S, p.tex_uv, rt_f2i32_sat(nd2.z)) * 2.0f - rt3_splat(1.0f);
+      rt3 T = rt_normalize(b.e1);
+      rt3 B = rt_normalize(rt_cross(ln, T));
+      rt3 ln_mapped = rt_normalize(T * n_map.x + B * n_map.y + ln * n_map.z);
+      p.normal = rt_normalize(normal_to_world(m, ln_mapped));
+    }
+  }
+  p.geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+}
+
+template <bool DETAIL, bool LDS>
+__global__ __launch_bounds__(256) void k_pathtrace_persistent(DevScene S, DevFrame F, rt_scene_uniforms U,
+                                                              uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
+                                                              uint32_t n_tris_total, uint32_t n_inst_total) {
+  extern __shared__ f4 s_scene[];
+  TravMem M;
+  if (LDS) {
+    // stage the traversal records once per workgroup
+    const f4* gn = reinterpret_cast<const f4*>(S.nodes);
+    const f4* gt = reinterpret_cast<const f4*>(S.tri_geom);
+    const f4* gi = reinterpret_cast<const f4*>(S.inst_trav);
+    f4* ln = s_scene;
+    f4* lt = ln + 2 * n_nodes_total;
+    f4* li = lt + 3 * n_tris_total;
+    for (uint32_t i = threadIdx.x; i < 2 * n_nodes_total; i += 256) ln[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < 3 * n_tris_total; i += 256) lt[i] = gt[i];
+    for (uint32_t i = threadIdx.x; i < 4 * n_inst_total; i += 256) li[i] = gi[i];
+    __syncthreads();
+    M.nodes = ln;
+    M.tri_geom = lt;
+    M.inst_trav = li;
+  } else {
+    M.nodes = reinterpret_cast<const f4*>(S.nodes);
+    M.tri_geom = reinterpret_cast<const f4*>(S.tri_geom);
+    M.inst_trav = reinterpret_cast<const f4*>(S.inst_trav);
+  }
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tiles_x = (U.width + 7u) / 8u;
+  const uint32_t n_tiles = tiles_x * ((U.height + 7u) / 8u);
+  const rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+  const rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+  const rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+  const rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+  const float lens = U.camera.origin[3];
+
+  // wave-uniform work cursor: pixels [tile_pos, 64) of tile `tile` are still unassigned
+  uint32_t tile = 0xffffffffu, tile_pos = 64u;
+  bool work_left = true;
+
+  PathState p;
+  bool alive = false;       // lane owns a running path
+  bool have_pixel = false;  // lane owns a pixel whose samples are not all done
+  uint32_t cnt_ext = 0, cnt_shadow = 0, cnt_nodes = 0, cnt_tris = 0, cnt_shaded = 0;
+  p.pixel = 0; p.rng = 0; p.depth = 0; p.sample = 0; p.prev_pdf = 0.0f; p.specular = true; p.hit_t = 0.0f;
+  p.tri = 0; p.inst = 0;
+  p.ro = p.rd = p.throughput = p.radiance = p.col = p.normal = p.geom_n = p.albedo = rt3_splat(0.0f);
+  p.tex_uv = rt2_make(0.0f, 0.0f);
+
+  for (;;) {
+    // ------------------------------------------------------------ regenerate
+    // (a) wave-wide: every lane without a pixel takes the next unassigned one of the wave's tile.
+    //     All lanes execute this loop (busy lanes with need = false) so that the wave-uniform cursor
+    //     (tile, tile_pos, work_left) stays identical in every lane.
+    {
+      bool need = !alive && !have_pixel;
+      for (;;) {
+        const unsigned long long mask = __ballot(need);
+        if (mask == 0ull || !work_left) break;
+        if (tile_pos >= 64u) {
+          const int leader = __builtin_ctzll(mask);
+          uint32_t t = 0;
+          if (lane == (uint32_t)leader) t = atomicAdd(ticket, 1u);
+          t = __shfl(t, leader, 64);
+          if (t >= n_tiles) {
+            work_left = false;
+            break;
+          }
+          tile = t;
+          tile_pos = 0u;
+        }
+        // rank of this lane among the needy lanes
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const uint32_t slot = tile_pos + rank;
+        if (need && slot < 64u) {
+          const uint32_t x = (tile % tiles_x) * 8u + (slot & 7u);
+          const uint32_t y = (tile / tiles_x) * 8u + (slot >> 3);
+          need = false;
+          if (x < U.width && y < U.height && owns_row(F, y)) {
+            have_pixel = true;
+            p.pixel = y * U.width + x;
+            p.sample = 0u;
+            p.col = rt3_splat(0.0f);
+          }
+        }
+        tile_pos += (uint32_t)__builtin_popcountll(mask);
+      }
+    }
+    // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
+    if (!alive && have_pixel) {
+      const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
+      p.rng = init_rng(p.pixel, U.frame_count * F.spp + p.sample);
+      rt3 off = rt3_splat(0.0f);
+      if (lens > 0.0f) {
+        float r = rt_sqrt(rand_pcg(p.rng));
+        float theta = RT_TWO_PI * rand_pcg(p.rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+      p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      p.ro = cam_o + off;
+      p.throughput = rt3_splat(1.0f);
+      p.radiance = rt3_splat(0.0f);
+      p.prev_pdf = 0.0f;
+      p.specular = true;
+      p.depth = 0u;
+      // background pixel (or MAX_DEPTH = 0): the sample is black and ends at once
+      if (!(F.depth[p.pixel] >= 1.0f) && F.max_depth != 0u) {
+        float4 g = F.normal_id[p.pixel];
+        p.tri = rt_f2u(g.z);
+        p.inst = rt_f2u(g.w);
+        setup_surface(S, p, true, g.x, g.y, F.albedo[p.pixel]);
+        alive = true;
+      }
+    }
+    const bool running = alive;
+    bool path_done = have_pixel && !alive;  // background sample ends immediately
+
+    // ------------------------------------------------------------ shade one bounce
+    bool want_shadow = false, want_extend = false;
+    bool nee_valid = false;
+    rt3 sh_o = rt3_splat(0.0f), sh_d = rt3_splat(0.0f), nee = rt3_splat(0.0f);
+    float sh_tmax = 0.0f;
+    if (running) {
+      if (DETAIL) cnt_shaded++;
+      float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
+      const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
+      const rt3 hit_p = p.ro + p.rd * p.hit_t;
+      p.normal = (rt_dot(p.rd, p.normal) < 0.0f) ? p.normal : -p.normal;
+      p.geom_n = (rt_dot(p.rd, p.geom_n) < 0.0f) ? p.geom_n : -p.geom_n;
+      float metallic = d1.x, roughness = d1.y;
+      if (d2.y > -0.5f) {
+        rt3 mr = sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.y));
+        metallic *= mr.z;
+        roughness *= mr.y;
+      }
+      roughness = rt_max(roughness, 0.005f);
+      rt3 emissive = xyz(d3);
+      if (d2.w > -0.5f) emissive = emissive * sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.w));
+      const rt3 f0 = rt_mix3(rt3_splat(0.04f), p.albedo, metallic);
+
+      bool ended = false;
+      if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
+        rt3 em_val = (mat_type == 3u) ? p.albedo : emissive;
+        if (p.specular) {
+          p.radiance = p.radiance + p.throughput * em_val;
+        } else {
+          p.radiance = p.radiance + p.throughput * em_val *
+                                        power_heuristic(p.prev_pdf, light_pdf(S, U.light_count, p.tri, p.inst, p.hit_t, p.rd));
+        }
+        if (mat_type == 3u) ended = true;
+      }
+      if (!ended) {
+        if (mat_type != 2u) {  // NEE: the 3 draws happen here, the shadow ray is traced below
+          LightSample ls = sample_light(S, U.light_count, hit_p, p.rng);
+          if (ls.pdf > 0.0f) {
+            rt3 bsdf_val = rt3_splat(0.0f);
+            float bsdf_pdf = 0.0f;
+            if (mat_type == 0u) {
+              bsdf_val = p.albedo / RT_PI;
+              bsdf_pdf = rt_max(rt_dot(p.normal, ls.dir), 0.0f) / RT_PI;
+            } else if (mat_type == 1u) {
+              bsdf_val = eval_ggx(p.normal, -p.rd, ls.dir, roughness, f0);
+              rt3 H = rt_normalize(-p.rd + ls.dir);
+              bsdf_pdf = (ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f)) /
+                         (4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
+            }
+            want_shadow = true;  // the reference traces the shadow ray before looking at bsdf_pdf
+            sh_o = hit_p + p.geom_n * 1e-4f;
+            sh_d = ls.dir;
+            sh_tmax = ls.dist - 2e-4f;
+            nee_valid = bsdf_pdf > 0.0f;
+            if (nee_valid) {
+              nee = p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                    rt_max(rt_dot(p.normal, ls.dir), 0.0f) / ls.pdf;
+            }
+          }
+        }
+        Scatter sc;
+        if (mat_type == 0u) {
+          sc = sample_diffuse(p.normal, p.albedo, p.rng);
+        } else if (mat_type == 1u) {
+          sc = sample_ggx(p.normal, -p.rd, roughness, f0, p.rng);
+        } else {
+          sc = sample_dielectric(p.rd, p.normal, d1.z, p.albedo, p.rng);
+        }
+        if (mat_type != 2u && rt_dot(sc.dir, p.geom_n) <= 0.0f) {
+          sc.pdf = 0.0f;
+          sc.throughput = rt3_splat(0.0f);
+        }
+        if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) {
+          ended = true;
+        } else {
+          p.throughput = p.throughput * sc.throughput;
+          rt3 offset_n = (rt_dot(sc.dir, p.geom_n) > 0.0f) ? p.geom_n : -p.geom_n;
+          p.ro = hit_p + offset_n * 1e-4f;
+          p.rd = sc.dir;
+          p.prev_pdf = sc.pdf;
+          p.specular = sc.specular;
+          if (p.depth > 3u) {
+            float pr = rt_max(p.throughput.x, rt_max(p.throughput.y, p.throughput.z));
+            if (rand_pcg(p.rng) > pr) {
+              ended = true;
+            } else {
+              p.throughput = p.throughput / pr;
+            }
+          }
+          if (!ended) {
+            if (p.depth < F.max_depth - 1u) {
+              want_extend = true;
+            } else {
+              ended = true;  // depth limit: the loop condition ends the path after this bounce
+            }
+          }
+        }
+      }
+      if (ended) path_done = true;
+    }
+
+    // ------------------------------------------------------------ shadow rays (any hit)
+    if (__ballot(want_shadow) != 0ull) {
+      float t_;
+      int32_t a_, b_;
+      bool occluded;
+      traverse<true, DETAIL>(M, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
+                             cnt_nodes, cnt_tris);
+      if (want_shadow) {
+        cnt_shadow++;
+        if (!occluded && nee_valid) p.radiance = p.radiance + nee;  // nothing is added when bsdf_pdf <= 0
+      }
+    }
+
+    // ------------------------------------------------------------ extension rays (closest hit)
+    if (__ballot(want_extend) != 0ull) {
+      float t_;
+      int32_t tri_, inst_;
+      bool any_;
+      traverse<false, DETAIL>(M, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
+                              cnt_nodes, cnt_tris);
+      if (want_extend) {
+        cnt_ext++;
+        if (inst_ < 0) {
+          path_done = true;
+        } else {
+          p.hit_t = t_;
+          p.tri = (uint32_t)tri_;
+          p.inst = (uint32_t)inst_;
+          setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+          p.depth++;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------ sample / pixel finished
+    if (path_done) {
+      alive = false;
+      p.col = p.col + p.radiance;
+      p.sample++;
+      if (p.sample >= F.spp) {
+        rt3 c = p.col / (float)F.spp;
+        float4 acc = make_float4(c.x, c.y, c.z, 1.0f);
+        if (U.frame_count > 1u) {
+          float4 prev = F.accum[p.pixel];
+          acc = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
+        }
+        F.accum[p.pixel] = acc;
+        have_pixel = false;
+      }
+    }
+    if (!work_left && __ballot(alive || have_pixel) == 0ull) break;
+  }
+
+  // counters: one flush per persistent wave
+  LaneCounters c;
+  c.primary = 0;
+  c.extension = cnt_ext;
+  c.shadow = cnt_shadow;
+  c.nodes = cnt_nodes;
+  c.tris = cnt_tris;
+  c.shaded = cnt_shaded;
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
 // ===================================================================== post process
 __device__ __forceinline__ rt3 pp_radiance(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :41-47
   int x = cx < 0 ? 0 : (cx > (int)U.width - 1 ? (int)U.width - 1 : cx);

@@ -64,6 +64,9 @@ struct rt_ctx {
   bool pipeline_built = false;
   bool detailed_counters = false;
   uint32_t stripe_rows = 0, stripe_rank = 0, stripe_count = 1;
+  int variant = 1;        // 1 = persistent waves + path regeneration (default), 0 = one-pixel-per-lane megakernel
+  int num_cus = 256;      // multiProcessorCount of the device
+  DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
 
   // kernel timing
   bool timing = false;
@@ -267,6 +270,13 @@ rt_ctx* rt_create(int device_ordinal) {
     return nullptr;
   }
   c->counters.capacity = c->counters.size = 2 * RT_COUNTER_SHARDS * 6 * sizeof(uint64_t);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+      c->num_cus = prop.multiProcessorCount;
+    (void)hipMalloc(&c->ticket.ptr, 256);
+    c->ticket.capacity = c->ticket.size = 256;
+  }
   (void)hipMemsetAsync(c->counters.ptr, 0, c->counters.size, c->stream);
   // lights buffer exists from the start with one dummy entry so that light_count == 0 scenes run
   (void)hipMalloc(&c->lights.ptr, 16);
@@ -282,7 +292,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->accum, &c->render_target,
-                         &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters};
+                         &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -491,13 +501,41 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
     hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles), dim3(64), 0, c->stream, S, Fp, c->uniforms);
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
   // 2. path trace
-  ev = next_events(c, 1);
-  if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-  if (c->detailed_counters)
-    hipLaunchKernelGGL(rtk::k_pathtrace<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
-  else
-    hipLaunchKernelGGL(rtk::k_pathtrace<false>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
-  if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  if (c->variant == 0) {
+    ev = next_events(c, 1);
+    if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    if (c->detailed_counters)
+      hipLaunchKernelGGL(rtk::k_pathtrace<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+    else
+      hipLaunchKernelGGL(rtk::k_pathtrace<false>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
+    if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  } else {
+    // persistent kernel: grid = resident workgroups, tiles handed out through a ticket counter
+    HIP_TRY(c, hipMemsetAsync(c->ticket.ptr, 0, 4, c->stream));
+    const size_t lds_bytes = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances) * 16;
+    const bool use_lds = lds_bytes <= 64 * 1024;
+    const size_t dyn = use_lds ? lds_bytes : 0;
+    const void* fn;
+    if (use_lds)
+      fn = c->detailed_counters ? (const void*)rtk::k_pathtrace_persistent<true, true>
+                                : (const void*)rtk::k_pathtrace_persistent<false, true>;
+    else
+      fn = c->detailed_counters ? (const void*)rtk::k_pathtrace_persistent<true, false>
+                                : (const void*)rtk::k_pathtrace_persistent<false, false>;
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn));
+    if (per_cu < 1) per_cu = 1;
+    uint32_t blocks = (uint32_t)per_cu * (uint32_t)c->num_cus;
+    const uint32_t max_useful = (tiles + 3) / 4;  // one tile per wave at least
+    if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+    uint32_t* ticket = (uint32_t*)c->ticket.ptr;
+    uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
+    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni};
+    ev = next_events(c, 1);
+    if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  }
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
 }
@@ -639,6 +677,11 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return RT_OK;
+}
+int rt_set_kernel_variant(rt_ctx* c, int variant) {
+  if (!c || variant < 0 || variant > 1) return RT_ERR_INVALID;
+  c->variant = variant;
   return RT_OK;
 }
 int rt_set_kernel_timing(rt_ctx* c, int enabled) {

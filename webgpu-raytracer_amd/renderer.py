@@ -54,6 +54,7 @@ def load_library(path=None):
         "rt_kernel_time_ms": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(u32)]),
         "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
+        "rt_set_kernel_variant": (i32, [vp, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
@@ -70,7 +71,7 @@ EXPORTED_SYMBOLS = (
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
-    "rt_set_kernel_timing rt_device_count").split()
+    "rt_set_kernel_timing rt_device_count rt_set_kernel_variant").split()
 
 
 def _ptr(a):
@@ -227,6 +228,10 @@ class WebGPURenderer:
 
     def setStream(self, hip_stream_handle):
         self._check(self.L.rt_set_stream(self.ctx, ctypes.c_void_p(hip_stream_handle)), "setStream")
+
+    def setKernelVariant(self, variant):
+        """1 = persistent waves + path regeneration (default), 0 = one pixel per lane megakernel"""
+        self._check(self.L.rt_set_kernel_variant(self.ctx, int(variant)), "setKernelVariant")
 
     def setKernelTiming(self, enabled):
         self._check(self.L.rt_set_kernel_timing(self.ctx, 1 if enabled else 0), "setKernelTiming")
