@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 runs: N compute() dispatches of one scene at a given size, no torch.
+usage: prof_frames.py [scene] [width] [height] [frames] [depth] [variant] [detailed]"""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import webgpu_raytracer_amd as W  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+depth = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+variant = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+detailed = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+
+b = W.WorldBridge()
+if scene == "viewer_diamond":
+    b.loadScene("viewer", "v 0 1 0\nv 1 0 0\nv 0 0 1\nv -1 0 0\nv 0 0 -1\nv 0 -1 0\n"
+                "f 1 3 2\nf 1 2 5\nf 1 5 4\nf 1 4 3\nf 6 2 3\nf 6 5 2\nf 6 4 5\nf 6 3 4\n")
+else:
+    b.loadScene(scene)
+r = W.WebGPURenderer(0)
+r.buildPipeline(depth, 1)
+W.upload_scene(r, b, w, h)
+r.setKernelVariant(variant)
+r.setCounting(bool(detailed))
+r.compute(1)
+r.sync()
+r.resetCounters()
+r.setKernelTiming(True)
+r.kernelTimeMs()
+t0 = time.perf_counter()
+for f in range(2, frames + 2):
+    r.compute(f)
+r.sync()
+dt = time.perf_counter() - t0
+k = r.kernelTimeMs()
+c = r.getCounters()
+rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
+print("scene=%s %dx%d frames=%d depth=%d variant=%d: %.3f ms/frame wall, pathtrace %.4f ms, primary %.4f ms, "
+      "%.1f Mrays/frame, %.1f Mrays/s" % (scene, w, h, frames, depth, variant, dt / frames * 1e3, k["pathtrace_ms"],
+                                          k["primary_ms"], rays / frames / 1e6, rays / dt / 1e6))
+print({kk: vv // frames for kk, vv in c.items()})
+if detailed:
+    print("pathtrace kernel only:", {kk: vv // frames for kk, vv in r.getKernelCounters(1).items()})

@@ -876,67 +876,174 @@ __device__ __forceinline__ LocalRay to_instance(const TravMem& M, uint32_t inst,
   return make_ray(lo, ld);
 }
 
-// One loop over TLAS and BLAS nodes. ANY = shadow ray (first hit ends), else closest hit.
-// `active` lanes trace; the others skip the loop (their exec bit is simply off).
+// Branch-free Möller–Trumbore: same operations and the same accept/reject truth table as
+// hit_triangle_raw (Raytracer.wgsl:443-453), evaluated without early exits so that a wave testing
+// 64 different triangles stays converged.
+__device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max, float& t_out) {
+  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
+  rt3 h = rt_cross(r.d, e2);
+  float a = rt_dot(e1, h);
+  float f = 1.0f / a;
+  rt3 s = r.o - v0;
+  float u = f * rt_dot(s, h);
+  rt3 q = rt_cross(s, e1);
+  float v = f * rt_dot(r.d, q);
+  float t = f * rt_dot(e2, q);
+  t_out = t;
+  bool reject = (rt_abs(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+  return !reject & (t > t_min) & (t < t_max);
+}
+
+// ---------------------------------------------------------------------------------------------
+// traverse(): one walk over TLAS and BLAS nodes for the 64 rays of a wave.
+//
+// Divergence control.  A lane is SEARCHING (walking nodes: slab tests, instance entry/exit) or
+// WAITING (it reached a BLAS leaf whose box it hits and has queued that leaf's triangles).  Every
+// trip of the loop lets all searching lanes take ONE node step.  When the queued triangle tests
+// reach a full wave's worth (or nobody is searching any more) the wave flushes the queue:
+//   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
+//     3-bit leaf counts, each owner also posts its instance-space ray;
+//   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
+//     with 6 triangles no longer holds 63 other lanes hostage;
+//   * each owner then folds its own results in leaf order with the reference's strict `t < closest`
+//     rule and goes back to searching.
+// Equivalence with the reference's sequential leaf loop (Raytracer.wgsl:474-482): a test is accepted
+// there iff geometry passes, t > t_min and t < the running closest; the running closest never exceeds
+// the closest at leaf entry, so testing every triangle against the leaf-entry bound in parallel and
+// re-applying `t < running closest` in order during the fold makes exactly the same decisions.
+// Per lane the sequence of visited nodes, tested triangles and tie-breaks is the reference's.
+// ANY = shadow ray (first accepted hit ends the ray), else closest hit.
+struct WaveWork {
+  f4* rays;         // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
+  uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
+};
+#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void traverse(const TravMem& M, uint32_t blas_base, bool active, rt3 o, rt3 d, float t_min,
-                                         float t_max, float& out_t, int32_t& out_tri, int32_t& out_inst, bool& out_any,
-                                         uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
+                                         rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
+                                         int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
+  const uint32_t lane = threadIdx.x & 63u;
   float closest = t_max;
   int32_t best_tri = -1, best_inst = -1;
   bool any = false;
-  if (active && blas_base != 0u) {
-    LocalRay r = make_ray(o, d);
-    const uint32_t tlas_end = rt_f2u(M.nodes[0].w);
-    uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
-    uint32_t cur_inst = 0u;
-    bool in_blas = false;
-    for (;;) {
+  bool searching = active && blas_base != 0u;
+  bool waiting = false;
+  uint32_t leaf = 0u;
+  LocalRay r = make_ray(o, d);
+  const uint32_t tlas_end = rt_f2u(M.nodes[0].w);
+  uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
+  uint32_t cur_inst = 0u;
+  bool in_blas = false;
+  for (;;) {
+#ifdef RT_WAVE_STATS
+    {
+      const bool any_search = __ballot(searching) != 0ull;
+      if (COUNT && lane == 0u && any_search) n_nodes++;  // wave-level node steps
+    }
+#endif
+    // ---- one node step for every searching lane
+    if (searching) {
       if (curr >= end) {
-        if (!in_blas) break;
-        in_blas = false;  // instance finished: back to the world-space ray and the TLAS cursor
-        r = make_ray(o, d);
-        curr = tlas_next;
-        end = tlas_end;
-        base = 0u;
-        continue;
-      }
-      f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
-      if (COUNT) n_nodes++;
-      uint32_t next = base + rt_f2u(lo.w);
-      if (hit_box4(lo, hi, r, t_min, closest)) {
-        const uint32_t data = rt_f2u(hi.w);
-        if (data == 0u) {
-          next = curr + 1u;
-        } else if (!in_blas) {
-          cur_inst = data >> 3;
-          uint32_t off;
-          r = to_instance(M, cur_inst, o, d, off);
-          tlas_next = next;
-          base = blas_base + off;
-          end = base + rt_f2u(M.nodes[2 * base].w);
-          next = base;
-          in_blas = true;
+        if (!in_blas || tlas_next >= tlas_end) {
+          searching = false;  // TLAS exhausted (or nothing left after this instance)
         } else {
-          const uint32_t first = data >> 3, count = data & 7u;
-          for (uint32_t i = 0; i < count; i++) {
-            const uint32_t tri = first + i;
-            if (COUNT) n_tris++;
-            float t = hit_tri4(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], r, t_min, closest);
-            if (t > 0.0f) {
-              if (ANY) {
-                any = true;
-                break;
-              }
-              closest = t;
-              best_tri = (int32_t)tri;
-              best_inst = (int32_t)cur_inst;
-            }
+          in_blas = false;  // instance finished: back to the world-space ray and the TLAS cursor
+          r = make_ray(o, d);
+          curr = tlas_next;
+          end = tlas_end;
+          base = 0u;
+        }
+      } else {
+        f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+#ifndef RT_WAVE_STATS
+        if (COUNT) n_nodes++;
+#endif
+        uint32_t next = base + rt_f2u(lo.w);
+        if (hit_box4(lo, hi, r, t_min, closest)) {
+          const uint32_t data = rt_f2u(hi.w);
+          if (data == 0u) {
+            next = curr + 1u;
+          } else if (!in_blas) {
+            cur_inst = data >> 3;
+            uint32_t off;
+            r = to_instance(M, cur_inst, o, d, off);
+            tlas_next = next;
+            base = blas_base + off;
+            end = base + rt_f2u(M.nodes[2 * base].w);
+            next = base;
+            in_blas = true;
+          } else {
+            leaf = data;
+            searching = false;
+            waiting = true;
           }
-          if (ANY && any) break;
+        }
+        curr = next;
+      }
+    }
+    // ---- flush the triangle queue?
+    const unsigned long long smask = __ballot(searching);
+    const unsigned long long wmask = __ballot(waiting);
+    if ((smask | wmask) == 0ull) break;
+    const uint32_t cnt = waiting ? (leaf & 7u) : 0u;
+    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                           4u * (uint32_t)__builtin_popcountll(b2);
+    if (wmask != 0ull && (total >= 64u || smask == 0ull)) {
+      const uint32_t excl =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+      if (waiting) {
+        f4 ra, rb;
+        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = t_min;
+        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
+        W.rays[2 * lane] = ra;
+        W.rays[2 * lane + 1] = rb;
+        const uint32_t first = leaf >> 3;
+        for (uint32_t i = 0; i < cnt; i++) W.items[excl + i] = (lane << 26) | (first + i);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = 0; c < total; c += 64u) {
+#ifdef RT_WAVE_STATS
+        if (COUNT && lane == 0u) n_tris++;  // wave-level 64-item chunks
+#endif
+        const uint32_t j = c + lane;
+        if (j < total) {
+          const uint32_t it = W.items[j];
+          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
+          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
+          LocalRay q;
+          q.o = rt3_make(ra.x, ra.y, ra.z);
+          q.d = rt3_make(rb.x, rb.y, rb.z);
+          float t;
+          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
+          W.items[j] = rt_f2u(ok ? t : -1.0f);
         }
       }
-      curr = next;
+      __builtin_amdgcn_wave_barrier();
+      if (waiting) {
+        const uint32_t first = leaf >> 3;
+        for (uint32_t i = 0; i < cnt; i++) {
+#ifndef RT_WAVE_STATS
+          if (COUNT) n_tris++;
+#endif
+          const float t = rt_u2f(W.items[excl + i]);
+          if (t > 0.0f && t < closest) {
+            if (ANY) {
+              any = true;
+              break;
+            }
+            closest = t;
+            best_tri = (int32_t)(first + i);
+            best_inst = (int32_t)cur_inst;
+          }
+        }
+        waiting = false;
+        searching = !(ANY && any);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   out_t = closest;
@@ -988,31 +1095,61 @@ __device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, b
   p.geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
 }
 
+// number of 16-byte LDS slots the whole scene needs (traversal records + shading arrays)
+__host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
+                                                  uint32_t n_lights) {
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)2 * n_verts +
+         ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2;
+}
+
 template <bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256) void k_pathtrace_persistent(DevScene S, DevFrame F, rt_scene_uniforms U,
+__global__ __launch_bounds__(256, 4) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
                                                               uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
-                                                              uint32_t n_tris_total, uint32_t n_inst_total) {
+                                                              uint32_t n_tris_total, uint32_t n_inst_total,
+                                                              uint32_t n_verts_total) {
   extern __shared__ f4 s_scene[];
+  // per-wave triangle work queue at the start of LDS, staged scene after it
+  WaveWork WW;
+  {
+    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+    WW.rays = reinterpret_cast<f4*>(wbase);
+    WW.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  }
+  f4* const s_records = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
   TravMem M;
+  DevScene S = Sg;
   if (LDS) {
-    // stage the traversal records once per workgroup
-    const f4* gn = reinterpret_cast<const f4*>(S.nodes);
-    const f4* gt = reinterpret_cast<const f4*>(S.tri_geom);
-    const f4* gi = reinterpret_cast<const f4*>(S.inst_trav);
-    f4* ln = s_scene;
-    f4* lt = ln + 2 * n_nodes_total;
-    f4* li = lt + 3 * n_tris_total;
-    for (uint32_t i = threadIdx.x; i < 2 * n_nodes_total; i += 256) ln[i] = gn[i];
-    for (uint32_t i = threadIdx.x; i < 3 * n_tris_total; i += 256) lt[i] = gt[i];
-    for (uint32_t i = threadIdx.x; i < 4 * n_inst_total; i += 256) li[i] = gi[i];
+    // Small scene: the whole scene (traversal records AND the arrays shading reads) lives in LDS,
+    // staged once per workgroup; only textures, the G-buffer and the accumulation buffer stay in HBM.
+    f4* dst = s_records;
+    auto stage = [&](const void* src, size_t slots) {
+      const f4* g = reinterpret_cast<const f4*>(src);
+      f4* base = dst;
+      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
+      dst += slots;
+      return base;
+    };
+    f4* ln = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    f4* lt = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    f4* li = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    S.topo = reinterpret_cast<const float4*>(stage(Sg.topo, (size_t)5 * n_tris_total));
+    S.pos = reinterpret_cast<const float4*>(stage(Sg.pos, n_verts_total));
+    S.nrm = reinterpret_cast<const float4*>(stage(Sg.nrm, n_verts_total));
+    // uv (8 B/vertex) and lights (8 B each): the device buffers are allocated with >= 16-byte slack
+    S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));
+    S.inst = reinterpret_cast<const float4*>(stage(Sg.inst, (size_t)9 * n_inst_total));
+    S.lights = reinterpret_cast<const uint2*>(stage(Sg.lights, ((size_t)Sg.n_lights + 1) / 2));
     __syncthreads();
     M.nodes = ln;
     M.tri_geom = lt;
     M.inst_trav = li;
+    S.nodes = reinterpret_cast<const float4*>(ln);
+    S.tri_geom = reinterpret_cast<const float4*>(lt);
+    S.inst_trav = reinterpret_cast<const float4*>(li);
   } else {
-    M.nodes = reinterpret_cast<const f4*>(S.nodes);
-    M.tri_geom = reinterpret_cast<const f4*>(S.tri_geom);
-    M.inst_trav = reinterpret_cast<const f4*>(S.inst_trav);
+    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
+    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
+    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
   }
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -1118,8 +1255,13 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(DevScene S, DevFra
     bool nee_valid = false;
     rt3 sh_o = rt3_splat(0.0f), sh_d = rt3_splat(0.0f), nee = rt3_splat(0.0f);
     float sh_tmax = 0.0f;
+#ifdef RT_WAVE_STATS
+    if (DETAIL && lane == 0u) cnt_shaded++;  // wave-level outer trips
+#endif
     if (running) {
+#ifndef RT_WAVE_STATS
       if (DETAIL) cnt_shaded++;
+#endif
       float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
       const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
       const rt3 hit_p = p.ro + p.rd * p.hit_t;
@@ -1214,12 +1356,18 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(DevScene S, DevFra
       if (ended) path_done = true;
     }
 
+#ifdef RT_EXP_NOSHADOW
+    want_shadow = false;  // timing experiment only
+#endif
+#ifdef RT_EXP_NOEXT
+    if (want_extend) { want_extend = false; path_done = true; }  // timing experiment only
+#endif
     // ------------------------------------------------------------ shadow rays (any hit)
     if (__ballot(want_shadow) != 0ull) {
       float t_;
       int32_t a_, b_;
       bool occluded;
-      traverse<true, DETAIL>(M, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
+      traverse<true, DETAIL>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
                              cnt_nodes, cnt_tris);
       if (want_shadow) {
         cnt_shadow++;
@@ -1232,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(DevScene S, DevFra
       float t_;
       int32_t tri_, inst_;
       bool any_;
-      traverse<false, DETAIL>(M, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
+      traverse<false, DETAIL>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
                               cnt_nodes, cnt_tris);
       if (want_extend) {
         cnt_ext++;

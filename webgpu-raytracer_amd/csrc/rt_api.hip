@@ -113,7 +113,8 @@ int ensure_buffer(rt_ctx* c, DeviceBuffer& b, size_t bytes, bool grow_policy) {
     cap = (cap + 3) & ~(size_t)3;
   }
   if (cap < 16) cap = 16;
-  HIP_TRY(c, hipMalloc(&b.ptr, cap));
+  // 16 bytes of slack beyond the reported capacity: kernels stage 8-byte arrays in 16-byte slots
+  HIP_TRY(c, hipMalloc(&b.ptr, cap + 16));
   b.capacity = cap;
   return 1;
 }
@@ -512,9 +513,9 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
   } else {
     // persistent kernel: grid = resident workgroups, tiles handed out through a ticket counter
     HIP_TRY(c, hipMemsetAsync(c->ticket.ptr, 0, 4, c->stream));
-    const size_t lds_bytes = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances) * 16;
-    const bool use_lds = lds_bytes <= 64 * 1024;
-    const size_t dyn = use_lds ? lds_bytes : 0;
+    const size_t lds_bytes = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
+    const bool use_lds = lds_bytes + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+    const size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + (use_lds ? lds_bytes : 0);  // work queues + records
     const void* fn;
     if (use_lds)
       fn = c->detailed_counters ? (const void*)rtk::k_pathtrace_persistent<true, true>
@@ -529,8 +530,8 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
     const uint32_t max_useful = (tiles + 3) / 4;  // one tile per wave at least
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
-    uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
-    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni};
+    uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts;
+    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv};
     ev = next_events(c, 1);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
