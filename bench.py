@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "tests")):
     if _p not in sys.path:
@@ -37,6 +39,7 @@ def cpu_baseline(pkg, bridge, frames):
     cpu.buildPipeline(DEPTH, 1)
     pkg.upload_scene(cpu, bridge, WIDTH, HEIGHT)
     cpu.setStripes(8, 0, 4)
+    sample_px = int(((np.arange(HEIGHT) // 8) % 4 == 0).sum()) * WIDTH
     cpu.resetCounters()
     t0 = time.perf_counter()
     for f in frames:
@@ -46,7 +49,7 @@ def cpu_baseline(pkg, bridge, frames):
     rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(cores), "kind": "port",
             "sample": "rows (y//8)%%4==0 (1/4 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s"
-                      % (WIDTH * HEIGHT // 4, len(frames), DEPTH, rays / 1e6, dt)}
+                      % (sample_px, len(frames), DEPTH, rays / 1e6, dt)}
 
 
 def main():
@@ -69,12 +72,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP renderer has no CPU fallback")
+    # Rehearsal switches for a 1-GPU box (never used by the driver): BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and BENCH_BACKEND=gloo reduces through host memory (RCCL refuses two ranks on one GPU).
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     bridge = pkg.WorldBridge()
     bridge.loadScene(SCENE)
@@ -82,7 +93,7 @@ def main():
     r.buildPipeline(DEPTH, 1)
     pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
     accum_t = rtdist.bind_torch_accum(r, device)
-    shard = rtdist.ShardedImage(r, rank, world, device_tensor=accum_t if world > 1 else None)
+    shard = rtdist.ShardedImage(r, rank, world, device_tensor=accum_t if (world > 1 and backend == "nccl") else None)
     frames = list(range(1, SPP_TOTAL + 1))
 
     def step():
@@ -111,7 +122,7 @@ def main():
 
     counts = r.getCounters()
     rays_local = counts["primary_rays"] + counts["extension_rays"] + counts["shadow_rays"]
-    stats = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=device)
+    stats = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,0 +1,64 @@
+"""The Node host (N-API addon + index.js) — north_star asks for the host side in the reference's own
+language.  CPU: the addon loads under the image's Node and its WorldBridge yields byte-identical bridge
+arrays.  GPU: a headless render driven from JavaScript is bit-identical to the CPU oracle."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE_DIR = os.path.join(REPO, "webgpu-raytracer_amd", "node")
+
+node = shutil.which("node")
+needs_node = pytest.mark.skipif(node is None or not os.path.exists("/usr/include/node/node_api.h"),
+                                reason="node / node_api.h not present")
+
+
+@pytest.fixture(scope="module")
+def addon(W):
+    W._build.build_rt()
+    path = W._build.build_node_addon()
+    assert path and os.path.exists(path)
+    return path
+
+
+@needs_node
+def test_addon_loads_and_world_arrays_match_python(W, addon):
+    js = ("const {WorldBridge}=require('%s/index.js');const c=require('crypto');(async()=>{const b=new WorldBridge();"
+          "await b.loadScene('cornell');b.updateCamera(512,512);const o={};"
+          "for(const k of ['vertices','normals','uvs','mesh_topology','tlas','blas','instances','lights','draw_commands','cameraData'])"
+          "o[k]=c.createHash('sha256').update(Buffer.from(b[k].buffer)).digest('hex');console.log(JSON.stringify(o));})()"
+          % NODE_DIR)
+    out = subprocess.run([node, "-e", js], check=True, capture_output=True, text=True).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    b = W.WorldBridge()
+    b.loadScene("cornell")
+    b.updateCamera(512, 512)
+    for k, digest in got.items():
+        assert hashlib.sha256(np.ascontiguousarray(getattr(b, k)).tobytes()).hexdigest() == digest, k
+
+
+@needs_node
+@pytest.mark.gpu
+def test_javascript_driven_render_matches_the_oracle(W, oracle_lib, addon):
+    out = subprocess.run([node, os.path.join(NODE_DIR, "render_cornell.js"), "cornell", "96", "80", "3", "4"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    b = W.WorldBridge()
+    b.loadScene("cornell")
+    cpu = oracle_lib.OracleRenderer()
+    cpu.buildPipeline(4, 1)
+    W.upload_scene(cpu, b, 96, 80)
+    for f in (1, 2, 3):
+        cpu.compute(f)
+        cpu.present()
+    assert hashlib.sha256(cpu.readAccum().tobytes()).hexdigest() == got["accum_sha256"]
+    assert hashlib.sha256(cpu.captureFrame()["data"].tobytes()).hexdigest() == got["rgba_sha256"]
+    c = cpu.getCounters()
+    assert got["counters"]["primary_rays"] == c["primary_rays"]
+    assert got["counters"]["extension_rays"] == c["extension_rays"]
+    assert got["counters"]["shadow_rays"] == c["shadow_rays"]

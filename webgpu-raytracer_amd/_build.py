@@ -81,10 +81,11 @@ def build_node_addon(force=False):
     hdr = "/usr/include/node/node_api.h"
     if not os.path.exists(src) or not os.path.exists(hdr):
         return None
-    if not force and _newer(NODE_ADDON, [src] + _headers()):
+    if not force and _newer(NODE_ADDON, [src, RT_LIB, SCENE_LIB] + _headers()):
         return NODE_ADDON
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I", "/usr/include/node", "-I", INCLUDE,
-           "-o", NODE_ADDON, src, "-ldl"]
+           "-o", NODE_ADDON, src, "-L", LIB_DIR, "-lmi355rt", "-lmi355scene",
+           "-Wl,-rpath,$ORIGIN/../lib"]
     subprocess.run(cmd, check=True)
     return NODE_ADDON
 

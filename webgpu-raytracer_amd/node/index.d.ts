@@ -1,0 +1,44 @@
+// TypeScript view of index.js: the method surface of the reference classes
+// (src/renderer/WebGPURenderer.ts:7-138, src/world-bridge.ts:4-216).
+export class WebGPURenderer {
+  constructor(device?: number);
+  readonly device: { queue: { onSubmittedWorkDone(): Promise<void> } };
+  init(): Promise<void>;
+  buildPipeline(depth: number, spp: number): void;
+  updateScreenSize(width: number, height: number): void;
+  resetAccumulation(): void;
+  loadTexturesFromWorld(bridge: WorldBridge): Promise<void>;
+  updateBuffer(type: "topology" | "instance" | "lights" | "draw_commands", data: Uint32Array | Float32Array): boolean;
+  updateCombinedGeometry(v: Float32Array, n: Float32Array, uv: Float32Array): boolean;
+  updateCombinedBVH(tlas: Float32Array, blas: Float32Array): boolean;
+  updateSceneUniforms(cameraData: Float32Array, frameCount: number, lightCount: number): void;
+  recreateBindGroup(): void;
+  compute(frameCount: number): void;
+  present(): void;
+  captureFrame(): Promise<{ data: ArrayBufferLike; width: number; height: number }>;
+  readAccum(): Float32Array;
+  getCounters(): Record<string, number>;
+  destroy(): void;
+}
+export class WorldBridge {
+  hasNewData: boolean;
+  hasNewGeometry: boolean;
+  initWasm(): Promise<void>;
+  loadScene(sceneName: string, objSource?: string, glbData?: Uint8Array): Promise<void>;
+  update(time: number): void;
+  updateCamera(width: number, height: number): void;
+  readonly vertices: Float32Array;
+  readonly normals: Float32Array;
+  readonly uvs: Float32Array;
+  readonly mesh_topology: Uint32Array;
+  readonly tlas: Float32Array;
+  readonly blas: Float32Array;
+  readonly instances: Float32Array;
+  readonly lights: Uint32Array;
+  readonly lightCount: number;
+  readonly draw_commands: Uint32Array;
+  readonly cameraData: Float32Array;
+  readonly textureCount: number;
+  readonly hasWorld: boolean;
+  getTextureRGBA(index: number): Uint8Array | undefined;
+}

@@ -1,0 +1,122 @@
+'use strict';
+// index.js — Node host: the reference's WebGPURenderer / WorldBridge class surface
+// (src/renderer/WebGPURenderer.ts:7-138, src/world-bridge.ts:4-216) over the N-API addon.
+// Plain CommonJS so that the Node 12 in this image runs it; index.d.ts carries the TypeScript
+// signatures of the reference classes.
+const path = require('path');
+const native = require(path.join(__dirname, 'mi355rt.node'));
+
+const KIND = { topology: 0, instance: 1, lights: 2, draw_commands: 3 };
+const RT_REALLOCATED = 1;
+
+class WebGPURenderer {
+  // `new WebGPURenderer(canvas)`: the canvas becomes a device ordinal (there is no swap chain).
+  constructor(device = 0) {
+    this._device = device;
+    this._ctx = null;
+    this.width = 0;
+    this.height = 0;
+    this._capture = null;
+  }
+  // only init() throws in the reference (WebGPUContext.ts:15,19)
+  async init() {
+    this._ctx = native.rtCreate(this._device);
+  }
+  get device() {
+    const self = this;
+    return { queue: { onSubmittedWorkDone: async () => { self._check(native.rtSync(self._ctx), 'sync'); } } };
+  }
+  _check(rc, what) {
+    if (rc < 0) throw new Error(`${what} failed (${rc}): ${native.rtLastError(this._ctx)}`);
+    return rc;
+  }
+  buildPipeline(depth, spp) { this._check(native.rtSetPipeline(this._ctx, depth, spp), 'buildPipeline'); }
+  updateScreenSize(width, height) {
+    this.width = width;
+    this.height = height;
+    this._check(native.rtResize(this._ctx, width, height), 'updateScreenSize');
+  }
+  resetAccumulation() { this._check(native.rtResetAccum(this._ctx), 'resetAccumulation'); }
+  async loadTexturesFromWorld(bridge) {
+    const n = bridge.textureCount;
+    if (n === 0) { this._check(native.rtUploadTextures(this._ctx, null, 0), 'loadTexturesFromWorld'); return; }
+    const layer = 1024 * 1024 * 4;
+    const all = new Uint8Array(n * layer);
+    for (let i = 0; i < n; i++) all.set(bridge.getTextureRGBA(i), i * layer);
+    this._check(native.rtUploadTextures(this._ctx, all, n), 'loadTexturesFromWorld');
+  }
+  updateBuffer(type, data) {
+    return this._check(native.rtUpload(this._ctx, KIND[type], data), `updateBuffer(${type})`) === RT_REALLOCATED;
+  }
+  updateCombinedGeometry(v, n, uv) {
+    return this._check(native.rtUploadGeometry(this._ctx, v, n, uv), 'updateCombinedGeometry') === RT_REALLOCATED;
+  }
+  updateCombinedBVH(tlas, blas) {
+    return this._check(native.rtUploadBVH(this._ctx, tlas, blas), 'updateCombinedBVH') === RT_REALLOCATED;
+  }
+  updateSceneUniforms(cameraData, frameCount, lightCount) {
+    this._check(native.rtSetScene(this._ctx, cameraData, frameCount, lightCount), 'updateSceneUniforms');
+  }
+  recreateBindGroup() {}
+  compute(frameCount) { this._check(native.rtCompute(this._ctx, frameCount), 'compute'); }
+  present() { this._check(native.rtPresent(this._ctx), 'present'); }
+  async captureFrame() {
+    if (!this.width) throw new Error('No render target');
+    const n = this.width * this.height * 4;
+    if (!this._capture || this._capture.length !== n) this._capture = new Uint8Array(n);  // reused between calls
+    this._check(native.rtCapture(this._ctx, this._capture), 'captureFrame');
+    return { data: this._capture.buffer, width: this.width, height: this.height };
+  }
+  // additions
+  readAccum() {
+    const out = new Float32Array(this.width * this.height * 4);
+    this._check(native.rtReadAccum(this._ctx, out), 'readAccum');
+    return out;
+  }
+  getCounters() {
+    const c = native.rtGetCounters(this._ctx);
+    return { primary_rays: c[0], extension_rays: c[1], shadow_rays: c[2], nodes_visited: c[3], tris_tested: c[4], shaded_hits: c[5] };
+  }
+  destroy() { if (this._ctx) { native.rtDestroy(this._ctx); this._ctx = null; } }
+}
+
+class WorldBridge {
+  constructor() { this._w = null; this._cache = {}; this.hasNewData = false; this.hasNewGeometry = false; this._wh = [-1, -1]; }
+  async initWasm() {}
+  async loadScene(sceneName, objSource, glbData) {
+    if (glbData) throw new Error('glTF/GLB input is out of scope');
+    if (this._w) native.msDestroy(this._w);
+    this._w = native.msCreate(sceneName, objSource === undefined ? null : objSource);
+    this._wh = [-1, -1];
+    this._refresh();
+    this.hasNewData = true;
+    this.hasNewGeometry = true;
+  }
+  update(time) { native.msUpdate(this._w, time); this._refresh(); this.hasNewData = true; this.hasNewGeometry = true; }
+  updateCamera(width, height) {
+    if (this._wh[0] === width && this._wh[1] === height) return;
+    this._wh = [width, height];
+    native.msUpdateCamera(this._w, width, height);
+    this._cache.camera = native.msGet(this._w, 'camera');
+  }
+  _refresh() {
+    for (const k of ['vertices', 'normals', 'uvs', 'mesh_topology', 'tlas', 'blas', 'instances', 'lights', 'draw_commands', 'camera'])
+      this._cache[k] = native.msGet(this._w, k);
+  }
+  get vertices() { return this._cache.vertices; }
+  get normals() { return this._cache.normals; }
+  get uvs() { return this._cache.uvs; }
+  get mesh_topology() { return this._cache.mesh_topology; }
+  get tlas() { return this._cache.tlas; }
+  get blas() { return this._cache.blas; }
+  get instances() { return this._cache.instances; }
+  get lights() { return this._cache.lights; }
+  get lightCount() { return this._cache.lights.length / 2; }
+  get draw_commands() { return this._cache.draw_commands; }
+  get cameraData() { return this._cache.camera; }
+  get textureCount() { return this._w ? native.msTextureCount(this._w) : 0; }
+  get hasWorld() { return !!this._w && this._cache.vertices.length > 0; }
+  getTextureRGBA(i) { return native.msTexture(this._w, i); }
+}
+
+module.exports = { WebGPURenderer, WorldBridge, native };
