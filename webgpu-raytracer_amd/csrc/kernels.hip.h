@@ -942,45 +942,43 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
       if (COUNT && lane == 0u && any_search) n_nodes++;  // wave-level node steps
     }
 #endif
-    // ---- one node step for every searching lane
-    if (searching) {
-      if (curr >= end) {
-        if (!in_blas || tlas_next >= tlas_end) {
-          searching = false;  // TLAS exhausted (or nothing left after this instance)
-        } else {
-          in_blas = false;  // instance finished: back to the world-space ray and the TLAS cursor
-          r = make_ray(o, d);
-          curr = tlas_next;
-          end = tlas_end;
-          base = 0u;
-        }
+    // ---- range exhausted (rare): leave the instance, or finish
+    if (searching && curr >= end) {
+      if (in_blas && tlas_next < tlas_end) {
+        in_blas = false;  // back to the world-space ray and the TLAS cursor
+        r = make_ray(o, d);
+        curr = tlas_next;
+        end = tlas_end;
+        base = 0u;
       } else {
-        f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
-#ifndef RT_WAVE_STATS
-        if (COUNT) n_nodes++;
-#endif
-        uint32_t next = base + rt_f2u(lo.w);
-        if (hit_box4(lo, hi, r, t_min, closest)) {
-          const uint32_t data = rt_f2u(hi.w);
-          if (data == 0u) {
-            next = curr + 1u;
-          } else if (!in_blas) {
-            cur_inst = data >> 3;
-            uint32_t off;
-            r = to_instance(M, cur_inst, o, d, off);
-            tlas_next = next;
-            base = blas_base + off;
-            end = base + rt_f2u(M.nodes[2 * base].w);
-            next = base;
-            in_blas = true;
-          } else {
-            leaf = data;
-            searching = false;
-            waiting = true;
-          }
-        }
-        curr = next;
+        searching = false;
       }
+    }
+    // ---- one node step for every searching lane (curr < end holds); select-based, two branches only
+    if (searching) {
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+#ifndef RT_WAVE_STATS
+      if (COUNT) n_nodes++;
+#endif
+      const bool hit = hit_box4(lo, hi, r, t_min, closest);
+      const uint32_t data = rt_f2u(hi.w);
+      const bool leafhit = hit && data != 0u;
+      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
+      const bool got_leaf = leafhit && in_blas;
+      if (leafhit && !in_blas) {  // TLAS leaf: enter the instance
+        cur_inst = data >> 3;
+        uint32_t off;
+        r = to_instance(M, cur_inst, o, d, off);
+        tlas_next = next;
+        base = blas_base + off;
+        end = base + rt_f2u(M.nodes[2 * base].w);
+        next = base;
+        in_blas = true;
+      }
+      leaf = got_leaf ? data : leaf;
+      waiting = got_leaf;
+      searching = !got_leaf;
+      curr = next;
     }
     // ---- flush the triangle queue?
     const unsigned long long smask = __ballot(searching);
@@ -995,14 +993,17 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
           __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
           2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
           4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+      const uint32_t first = leaf >> 3;
       if (waiting) {
         f4 ra, rb;
         ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = t_min;
         rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
         W.rays[2 * lane] = ra;
         W.rays[2 * lane + 1] = rb;
-        const uint32_t first = leaf >> 3;
-        for (uint32_t i = 0; i < cnt; i++) W.items[excl + i] = (lane << 26) | (first + i);
+        const uint32_t tag = lane << 26;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++)
+          if (i < cnt) W.items[excl + i] = tag | (first + i);
       }
       __builtin_amdgcn_wave_barrier();
       for (uint32_t c = 0; c < total; c += 64u) {
@@ -1024,20 +1025,25 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
       }
       __builtin_amdgcn_wave_barrier();
       if (waiting) {
-        const uint32_t first = leaf >> 3;
-        for (uint32_t i = 0; i < cnt; i++) {
+        // fold this lane's results in leaf order (strict t < closest: the first of equal hits wins)
+        bool stop = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++) {
+          if (i < cnt && !stop) {
 #ifndef RT_WAVE_STATS
-          if (COUNT) n_tris++;
+            if (COUNT) n_tris++;
 #endif
-          const float t = rt_u2f(W.items[excl + i]);
-          if (t > 0.0f && t < closest) {
-            if (ANY) {
-              any = true;
-              break;
+            const float t = rt_u2f(W.items[excl + i]);
+            if (t > 0.0f && t < closest) {
+              if (ANY) {
+                any = true;
+                stop = true;
+              } else {
+                closest = t;
+                best_tri = (int32_t)(first + i);
+                best_inst = (int32_t)cur_inst;
+              }
             }
-            closest = t;
-            best_tri = (int32_t)(first + i);
-            best_inst = (int32_t)cur_inst;
           }
         }
         waiting = false;
