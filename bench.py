@@ -10,7 +10,7 @@ N > 1    : the image is split into interleaved 16-row stripes across ranks (stro
            image), one RCCL sum-reduce of the float4 accumulation buffer to rank 0 per image.
 Extra    : "roofline" for the dominant kernel (k_pathtrace; HIP events inside the C library, on the
            stream the kernel runs on) and "cpu_baseline" (the CPU oracle timed on a bounded
-           1/4 row-interleaved sample of the same workload, rank 0 at N = 1 only).
+           1/3 row-interleaved sample of the same workload, rank 0 at N = 1 only).
 """
 import argparse
 import json
@@ -32,14 +32,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def cpu_baseline(pkg, bridge, frames):
     """Time the CPU oracle (C++ scalar restatement, all host threads) on rows
-    {y : (y // 8) % 16 == 0} of the same 1080p frames: a 1/16 row-interleaved sample."""
+    {y : (y // 8) % 3 == 0} of the same 1080p frames: a 1/3 row-interleaved sample."""
     import oracle_lib
     cpu = oracle_lib.OracleRenderer()
     cores = oracle_lib.lib().oracle_hardware_threads()
     cpu.buildPipeline(DEPTH, 1)
     pkg.upload_scene(cpu, bridge, WIDTH, HEIGHT)
-    cpu.setStripes(8, 0, 4)
-    sample_px = int(((np.arange(HEIGHT) // 8) % 4 == 0).sum()) * WIDTH
+    cpu.setStripes(8, 0, 3)
+    sample_px = int(((np.arange(HEIGHT) // 8) % 3 == 0).sum()) * WIDTH
     cpu.resetCounters()
     t0 = time.perf_counter()
     for f in frames:
@@ -48,7 +48,7 @@ def cpu_baseline(pkg, bridge, frames):
     c = cpu.getCounters()
     rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(cores), "kind": "port",
-            "sample": "rows (y//8)%%4==0 (1/4 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s"
+            "sample": "rows (y//8)%%3==0 (1/3 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s"
                       % (sample_px, len(frames), DEPTH, rays / 1e6, dt)}
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # time the persistent kernel at several forced occupancies (waves/SIMD)
-for w in 3 4 5 6 8; do
+for w in 3 4 5; do
 python - <<PY
 import re, webgpu_raytracer_amd as W
 p="webgpu-raytracer_amd/csrc/kernels.hip.h"

@@ -43,6 +43,9 @@ struct DevFrame {
   uint64_t* counters;   // 6 x u64
   uint32_t max_depth, spp;
   uint32_t stripe_rows, stripe_rank, stripe_count;
+  // dense enumeration of the tile rows this rank owns (set when stripe_rows % 8 == 0, else own_period = 0):
+  // k-th owned tile row = (k / own_run) * own_period + own_first + (k % own_run); own_tile_rows of them exist
+  uint32_t own_run, own_period, own_first, own_tile_rows;
 };
 
 struct DevPost {

@@ -899,8 +899,8 @@ __device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& 
 //
 // Divergence control.  A lane is SEARCHING (walking nodes: slab tests, instance entry/exit) or
 // WAITING (it reached a BLAS leaf whose box it hits and has queued that leaf's triangles).  Every
-// trip of the loop lets all searching lanes take ONE node step.  When the queued triangle tests
-// reach a full wave's worth (or nobody is searching any more) the wave flushes the queue:
+// trip of the loop lets all searching lanes take ONE node step.  When enough triangle tests are queued
+// (RT_FLUSH_ITEMS) or nobody is searching any more, the wave flushes the queue:
 //   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
 //     3-bit leaf counts, each owner also posts its instance-space ray;
 //   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
@@ -918,6 +918,10 @@ struct WaveWork {
   uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
 };
 #define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#ifndef RT_FLUSH_ITEMS
+#define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
+                            // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
+#endif
 
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
@@ -988,7 +992,7 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
     const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
     const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
                            4u * (uint32_t)__builtin_popcountll(b2);
-    if (wmask != 0ull && (total >= 64u || smask == 0ull)) {
+    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
       const uint32_t excl =
           __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
           2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
@@ -1160,7 +1164,8 @@ __global__ __launch_bounds__(256, 4) void k_pathtrace_persistent(DevScene Sg, De
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (U.width + 7u) / 8u;
-  const uint32_t n_tiles = tiles_x * ((U.height + 7u) / 8u);
+  // tickets enumerate only the tile rows this rank owns when the stripes are tile-aligned
+  const uint32_t n_tiles = tiles_x * (F.own_period ? F.own_tile_rows : (U.height + 7u) / 8u);
   const rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
   const rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
   const rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
@@ -1207,8 +1212,10 @@ __global__ __launch_bounds__(256, 4) void k_pathtrace_persistent(DevScene Sg, De
             __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         const uint32_t slot = tile_pos + rank;
         if (need && slot < 64u) {
+          uint32_t trow = tile / tiles_x;
+          if (F.own_period) trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
           const uint32_t x = (tile % tiles_x) * 8u + (slot & 7u);
-          const uint32_t y = (tile / tiles_x) * 8u + (slot >> 3);
+          const uint32_t y = trow * 8u + (slot >> 3);
           need = false;
           if (x < U.width && y < U.height && owns_row(F, y)) {
             have_pixel = true;

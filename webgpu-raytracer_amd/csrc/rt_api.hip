@@ -489,6 +489,17 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
   F.stripe_rows = c->stripe_rows;
   F.stripe_rank = c->stripe_rank;
   F.stripe_count = c->stripe_count;
+  F.own_run = F.own_period = F.own_first = F.own_tile_rows = 0;
+  if (c->stripe_count > 1 && c->stripe_rows && c->stripe_rows % 8 == 0) {
+    const uint32_t tile_rows = (c->height + 7) / 8;
+    F.own_run = c->stripe_rows / 8;
+    F.own_period = F.own_run * c->stripe_count;
+    F.own_first = F.own_run * c->stripe_rank;
+    uint32_t owned = 0;
+    for (uint32_t ty = 0; ty < tile_rows; ty++)
+      if ((ty / F.own_run) % c->stripe_count == c->stripe_rank) owned++;
+    F.own_tile_rows = owned;
+  }
 
   DevFrame Fp = F;  // the primary kernel counts into bank 0, the path tracer into bank 1
   F.counters = (uint64_t*)c->counters.ptr + (size_t)RT_COUNTER_SHARDS * 6;
@@ -527,7 +538,8 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn));
     if (per_cu < 1) per_cu = 1;
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)c->num_cus;
-    const uint32_t max_useful = (tiles + 3) / 4;  // one tile per wave at least
+    const uint32_t own_tiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;
+    const uint32_t max_useful = (own_tiles + 3) / 4;  // one tile per wave at least
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
     uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts;
