@@ -146,13 +146,16 @@ def main():
         alg_bytes = (32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"] + 344.0 * kc["shaded_hits"]) / n_launch \
             + (32.0 + 24.0) * owned_px  # accumulation read+write, G-buffer read
         achieved = alg_bytes / (ktime["pathtrace_ms"] * 1e-3) / 1e9 if ktime["pathtrace_ms"] > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch from the PMC passes committed under profiles/ (collected by tools/make_profiles.sh,
+        # N = 1 only; counters cannot be read from inside this process)
+        traffic, pmc = None, {}
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_pathtrace_bytes_per_launch")
+                pmc = json.load(open(tpath))
+                traffic = pmc.get("k_pathtrace_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
         out = {
             "metric": "Mrays/s (primary+secondary) at 1920x1080 SPP=64 depth=8",
             "value": round(rays_total / elapsed / 1e6, 2),
@@ -175,7 +178,11 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "avg_launch_ms": round(ktime["pathtrace_ms"], 4),
                          "avg_primary_ms": round(ktime["primary_ms"], 4), "launches": ktime["launches"],
-                         "alg_bytes_per_launch": int(alg_bytes)},
+                         "alg_bytes_per_launch": int(alg_bytes),
+                         "note": "algorithmic gather bytes (SURVEY 8d) are served by LDS/L1, so achieved can exceed the HBM "
+                                 "peak; the kernel is VALU-issue bound",
+                         "valu_busy_frac": pmc.get("valu_busy_frac"),
+                         "valu_lane_utilization": pmc.get("valu_lane_utilization")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, bridge, frames)
