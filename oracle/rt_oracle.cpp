@@ -818,7 +818,13 @@ struct Oracle {
   rt3 get_radiance_bilinear(float u, float v) const {  // :71-83
     float fx = u * (float)scene.width - 0.5f, fy = v * (float)scene.height - 0.5f;
     float flx = rt_floor(fx), fly = rt_floor(fy);
-    int ix = rt_f2i32_sat(flx), iy = rt_f2i32_sat(fly);
+    // i32(floor(f)), kept within +-2^30 so that the +-1 offsets below cannot overflow a signed int; every
+    // coordinate is clamped to the image in get_radiance, so no result changes
+    auto texel = [](float f) {
+      int i = rt_f2i32_sat(f);
+      return i < -1073741824 ? -1073741824 : (i > 1073741823 ? 1073741823 : i);
+    };
+    int ix = texel(flx), iy = texel(fly);
     float wx = fx - flx, wy = fy - fly;
     rt3 c00 = get_radiance_clean(ix, iy), c10 = get_radiance_clean(ix + 1, iy);
     rt3 c01 = get_radiance_clean(ix, iy + 1), c11 = get_radiance_clean(ix + 1, iy + 1);

@@ -87,6 +87,16 @@ def test_recorder_semantics_frame_count_from_zero(W, oracle_lib, gpu_renderer):
     assert acc[..., 3].max() == 3.0  # N-1 samples accumulated
 
 
+def test_present_with_recorder_frame_zero(W, oracle_lib, gpu_renderer):
+    """present() at frame_count 0 (the recorder's warm-up, VideoRecorder.ts:164-169): alpha = 1/0 and the average
+    jitter is non-finite, so the un-jitter footprint leaves the LDS tile and the direct path must take over."""
+    b = pu.bridge_for(W, "cornell")
+    cpu = oracle_lib.OracleRenderer()
+    for r in (gpu_renderer, cpu):
+        pu.drive(r, W, b, 48, 40, 4, 1, (0, 1, 2, 3), present=True)
+    pu.assert_parity(gpu_renderer, cpu, check_output=True)
+
+
 def test_accumulation_round_trip_and_reset(W, gpu_renderer):
     b = pu.bridge_for(W, "cornell")
     pu.drive(gpu_renderer, W, b, 64, 48, 4, 1, (1, 2), present=False)

@@ -1447,6 +1447,13 @@ __device__ __forceinline__ rt3 pp_radiance(const DevPost& P, const rt_scene_unif
   if (a.w <= 0.0f) return rt3_splat(0.0f);
   return rt3_make(a.x, a.y, a.z) / a.w;
 }
+// i32(floor(f)) for a texel coordinate, kept within +-2^30 so that the +-1 / tile-origin arithmetic that
+// follows cannot overflow (every coordinate is clamped to the image afterwards, so this changes no result;
+// a non-finite average jitter at frame_count == 0 does produce such values)
+__device__ __forceinline__ int pp_texel(float f) {
+  int i = rt_f2i32_sat(f);
+  return i < -1073741824 ? -1073741824 : (i > 1073741823 ? 1073741823 : i);
+}
 __device__ rt3 pp_clean(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :49-68
   rt3 center = pp_radiance(P, U, cx, cy);
   rt3 max_nb = rt3_splat(-1e6f);
@@ -1463,7 +1470,7 @@ __device__ rt3 pp_nearest(const DevPost& P, const rt_scene_uniforms& U, int cx, 
   float v = ((float)cy + 0.5f) / (float)U.height - U.average_jitter[1];
   float fx = u * (float)U.width - 0.5f, fy = v * (float)U.height - 0.5f;
   float flx = rt_floor(fx), fly = rt_floor(fy);
-  int ix = rt_f2i32_sat(flx), iy = rt_f2i32_sat(fly);
+  int ix = pp_texel(flx), iy = pp_texel(fly);
   float wx = fx - flx, wy = fy - fly;
   rt3 c00 = pp_clean(P, U, ix, iy), c10 = pp_clean(P, U, ix + 1, iy);
   rt3 c01 = pp_clean(P, U, ix, iy + 1), c11 = pp_clean(P, U, ix + 1, iy + 1);
@@ -1476,24 +1483,97 @@ __device__ __forceinline__ rt3 aces(rt3 color) {  // :36-39
   return rt_clamp3(num / den, rt3_splat(0.0f), rt3_splat(1.0f));
 }
 
-// Straight restatement: every get_radiance_nearest re-derives its footprint from the accumulation
-// buffer (served by L1/L2; the footprint of a 16x16 block is 22x22 pixels).
+// k_postprocess: LDS-tiled.  A 16x16 block needs get_radiance_nearest on an 18x18 region; each of those
+// is (frame_count <= 16) a bilinear blend of get_radiance_clean at 4 texels or (later) one of them, and
+// each clean value looks at a 3x3 neighbourhood of get_radiance.  As written in the WGSL that is 171 / 684
+// accumulation-buffer reads per pixel; here the three levels are materialised once per block in LDS
+// (22x22 radiance -> 20x20 clean -> 18x18 nearest), so each accumulation texel is read ~1.9x (halo) and
+// the rest is LDS traffic.  Every value is computed by the same function as the straight form, so the
+// output is bit-identical; a bilinear footprint that falls outside the tile (possible only for
+// |average_jitter| > 0.5 px or the non-finite jitter of frame_count == 0) falls back to the direct path.
+#define PP_B 16
+#define PP_R (PP_B + 6)  // radiance tile edge, origin at block - 3
+#define PP_C (PP_B + 4)  // clean tile edge, origin at block - 2
+#define PP_N (PP_B + 2)  // nearest tile edge, origin at block - 1
 __global__ __launch_bounds__(256) void k_postprocess(DevPost P, rt_scene_uniforms U) {
-  const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
-  const uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
-  if (x >= U.width || y >= U.height) return;
-  const int ix = (int)x, iy = (int)y;
-  rt3 nb[9];
-  for (int dy = -1; dy <= 1; dy++)
-    for (int dx = -1; dx <= 1; dx++) nb[(dy + 1) * 3 + (dx + 1)] = pp_nearest(P, U, ix + dx, iy + dy);
-  rt3 center_color = nb[4];
+  __shared__ float s_rad[PP_R * PP_R * 3];
+  __shared__ float s_clean[PP_C * PP_C * 3];
+  __shared__ float s_near[PP_N * PP_N * 3];
+  const int bx = (int)blockIdx.x * PP_B, by = (int)blockIdx.y * PP_B;
+  const int tid = (int)threadIdx.x;
 
+  // level 0: radiance (get_radiance clamps the coordinate, so the halo holds edge-replicated values)
+  for (int i = tid; i < PP_R * PP_R; i += 256) {
+    rt3 v = pp_radiance(P, U, bx - 3 + i % PP_R, by - 3 + i / PP_R);
+    s_rad[3 * i] = v.x; s_rad[3 * i + 1] = v.y; s_rad[3 * i + 2] = v.z;
+  }
+  __syncthreads();
+  // level 1: firefly-clamped radiance
+  for (int i = tid; i < PP_C * PP_C; i += 256) {
+    const int lx = i % PP_C + 1, ly = i / PP_C + 1;  // position in the radiance tile
+    auto rad = [&](int x, int y) {
+      const float* q = &s_rad[3 * (y * PP_R + x)];
+      return rt3_make(q[0], q[1], q[2]);
+    };
+    rt3 center = rad(lx, ly);
+    rt3 max_nb = rt3_splat(-1e6f);
+    for (int y = -1; y <= 1; y++)
+      for (int x = -1; x <= 1; x++) {
+        if (x == 0 && y == 0) continue;
+        max_nb = rt_max3(max_nb, rad(lx + x, ly + y));
+      }
+    rt3 c = rt_clamp3(center, rt3_splat(0.0f), max_nb * 3.0f + rt3_splat(0.1f));
+    s_clean[3 * i] = c.x; s_clean[3 * i + 1] = c.y; s_clean[3 * i + 2] = c.z;
+  }
+  __syncthreads();
+  // level 2: un-jittered ("nearest") radiance
+  for (int i = tid; i < PP_N * PP_N; i += 256) {
+    const int cx = bx - 1 + i % PP_N, cy = by - 1 + i / PP_N;
+    auto clean = [&](int gx, int gy, bool& inside) {
+      const int lx = gx - (bx - 2), ly = gy - (by - 2);
+      inside = lx >= 0 && ly >= 0 && lx < PP_C && ly < PP_C;
+      const float* q = &s_clean[3 * ((inside ? ly : 0) * PP_C + (inside ? lx : 0))];
+      return rt3_make(q[0], q[1], q[2]);
+    };
+    rt3 v;
+    bool ok;
+    if (U.frame_count > 16u) {
+      v = clean(cx, cy, ok);  // always inside
+    } else {
+      float u = ((float)cx + 0.5f) / (float)U.width - U.average_jitter[0];
+      float w = ((float)cy + 0.5f) / (float)U.height - U.average_jitter[1];
+      float fx = u * (float)U.width - 0.5f, fy = w * (float)U.height - 0.5f;
+      float flx = rt_floor(fx), fly = rt_floor(fy);
+      int ix = pp_texel(flx), iy = pp_texel(fly);
+      float wx = fx - flx, wy = fy - fly;
+      bool i00, i11;
+      bool i10, i01;
+      rt3 c00 = clean(ix, iy, i00), c10 = clean(ix + 1, iy, i10);
+      rt3 c01 = clean(ix, iy + 1, i01), c11 = clean(ix + 1, iy + 1, i11);
+      if (i00 && i10 && i01 && i11) {
+        v = rt_mix3(rt_mix3(c00, c10, wx), rt_mix3(c01, c11, wx), wy);
+      } else {
+        v = pp_nearest(P, U, cx, cy);  // footprint left the tile: straight path, same arithmetic
+      }
+    }
+    s_near[3 * i] = v.x; s_near[3 * i + 1] = v.y; s_near[3 * i + 2] = v.z;
+  }
+  __syncthreads();
+
+  const uint32_t x = (uint32_t)bx + (uint32_t)(tid & 15), y = (uint32_t)by + (uint32_t)(tid >> 4);
+  if (x >= U.width || y >= U.height) return;
+  const int lx = (tid & 15) + 1, ly = (tid >> 4) + 1;
+  auto nearest = [&](int dx, int dy) {
+    const float* q = &s_near[3 * ((ly + dy) * PP_N + lx + dx)];
+    return rt3_make(q[0], q[1], q[2]);
+  };
+  const rt3 center_color = nearest(0, 0);
   rt3 filtered_sum = rt3_splat(0.0f);
   float total_weight = 0.0f;
   rt3 m1 = rt3_splat(0.0f), m2 = rt3_splat(0.0f);
   for (int dy = -1; dy <= 1; dy++)
     for (int dx = -1; dx <= 1; dx++) {
-      rt3 ncol = nb[(dy + 1) * 3 + (dx + 1)];
+      rt3 ncol = nearest(dx, dy);
       float w_s = rt_exp(-(float)(dx * dx + dy * dy) / 0.5f);  // 2 * SIGMA_S^2 = 0.5
       rt3 cd = ncol - center_color;
       float w_r = rt_exp(-rt_dot(cd, cd) / 0.2f);  // 2 * SIGMA_R * RADIUS^2 = f32(0.1) * 2
