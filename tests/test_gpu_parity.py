@@ -184,3 +184,56 @@ def test_full_size_properties_1080p(W, oracle_lib, gpu_renderer):
     pu.drive(cpu, W, b, w, h, 8, 1, (1, 2, 3, 4), present=False)
     band = cpu.readAccum()[512:520]
     assert np.array_equal(band.view(np.uint32), a1[512:520].view(np.uint32))
+
+
+def test_scene_without_lights(W, oracle_lib, gpu_renderer):
+    """light_count == 0: sample_light_source returns before drawing (Raytracer.wgsl:346-349), so no NEE draws,
+    no shadow rays, and only directly visible emitters contribute."""
+    b = pu.bridge_for(W, "cornell")
+
+    class NoLights:
+        def __init__(self, inner):
+            self._b = inner
+        def __getattr__(self, k):
+            return getattr(self._b, k)
+        lights = np.zeros(0, dtype=np.uint32)
+        lightCount = 0
+
+    nb = NoLights(b)
+    cpu = oracle_lib.OracleRenderer()
+    for r in (gpu_renderer, cpu):
+        pu.drive(r, W, nb, 64, 64, 6, 1, (1, 2), present=True)
+    pu.assert_parity(gpu_renderer, cpu, check_output=True)
+    assert gpu_renderer.getCounters()["shadow_rays"] == 0
+
+
+def test_reupload_larger_scene_and_resize(W, oracle_lib, gpu_renderer):
+    """Scene swap on a live context: buffers grow (needsRebind), derived records are rebuilt, the screen is
+    re-allocated; the result must equal a fresh oracle run of the second scene (totalFrames carried over)."""
+    small, big = pu.bridge_for(W, "cornell"), pu.bridge_for(W, "special")
+    cpu = oracle_lib.OracleRenderer()
+    for r in (gpu_renderer, cpu):
+        pu.drive(r, W, small, 48, 48, 4, 1, (1, 2), present=True)
+        pu.drive(r, W, big, 80, 56, 8, 1, (1, 2, 3), present=True)   # same renderer: totalFrames keeps counting
+    pu.assert_parity(gpu_renderer, cpu, check_output=True)
+
+
+@pytest.mark.parametrize("scene,depth", [("instanced1000", 8), ("sponza_like", 8), ("glass_blob", 16)])
+def test_full_size_oracle_band(W, oracle_lib, gpu_renderer, scene, depth):
+    """BASELINE configs 3-5 at full resolution: the GPU renders the whole frame, the oracle only one 8-row band;
+    the band must agree bit for bit, the frame must be finite with the right sample count."""
+    b = pu.bridge_for(W, scene)
+    w, h = (1920, 1080) if scene != "glass_blob" else (3840, 2160)
+    frames = (1, 2)
+    pu.drive(gpu_renderer, W, b, w, h, depth, 1, frames, present=False, detailed=False)
+    acc = gpu_renderer.readAccum()
+    assert np.isfinite(acc).all() and (acc[..., 3] == len(frames)).all()
+    c = gpu_renderer.getCounters()
+    assert c["primary_rays"] == w * h * len(frames)
+    stripes = h // 8
+    band = stripes // 2
+    cpu = oracle_lib.OracleRenderer()
+    cpu.setStripes(8, band, stripes)
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
+    rows = slice(band * 8, band * 8 + 8)
+    assert np.array_equal(cpu.readAccum()[rows].view(np.uint32), acc[rows].view(np.uint32))
