@@ -1112,8 +1112,10 @@ __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_t
          ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2;
 }
 
+// Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
+// is latency bound and gains ~11 % from 6 waves/SIMD even with the spills that costs (measured on MI355X).
 template <bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256, 4) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
+__global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
                                                               uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
                                                               uint32_t n_tris_total, uint32_t n_inst_total,
                                                               uint32_t n_verts_total) {
