@@ -9,8 +9,9 @@ repo root) or through importlib.
 from . import _build
 from .world_bridge import WorldBridge
 from .renderer import WebGPURenderer, RendererError, upload_scene
+from .recorder import FrameLoop
 
-__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "build"]
+__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "FrameLoop", "build"]
 
 
 def build(force=False):
