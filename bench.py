@@ -79,9 +79,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"   # rehearsal: exercise the RCCL calls with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -93,7 +97,9 @@ def main():
     r.buildPipeline(DEPTH, 1)
     pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
     accum_t = rtdist.bind_torch_accum(r, device)
-    shard = rtdist.ShardedImage(r, rank, world, device_tensor=accum_t if (world > 1 and backend == "nccl") else None)
+    shard = rtdist.ShardedImage(r, rank, world,
+                                device_tensor=accum_t if ((world > 1 or force_dist) and backend == "nccl") else None)
+    shard.force_collective = force_dist
     frames = list(range(1, SPP_TOTAL + 1))
 
     def step():
@@ -102,7 +108,7 @@ def main():
         shard.gather(present=True)
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +129,7 @@ def main():
     counts = r.getCounters()
     rays_local = counts["primary_rays"] + counts["extension_rays"] + counts["shadow_rays"]
     stats = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
+    if world > 1 or force_dist:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rsum = stats[1:].clone()
@@ -187,7 +193,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, bridge, frames)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

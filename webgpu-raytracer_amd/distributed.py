@@ -25,6 +25,7 @@ class ShardedImage:
         self.world = world_size
         self.stripe_rows = stripe_rows
         self.device_tensor = device_tensor  # torch CUDA tensor aliasing the accumulation buffer, or None
+        self.force_collective = False       # rehearsal: run the collective even with one rank
         renderer.setStripes(stripe_rows, rank, world_size)
 
     def owned_rows(self, height):
@@ -37,7 +38,7 @@ class ShardedImage:
 
     def gather(self, present=True):
         """Sum the per-rank accumulation buffers onto rank 0; rank 0 then runs the post pass."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             import torch
             import torch.distributed as dist
             if self.device_tensor is not None:
