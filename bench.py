@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
     args = ap.parse_args()
 
     import torch
@@ -104,7 +106,7 @@ def main():
 
     def step():
         r.resetAccumulation()
-        shard.render(frames)
+        shard.render(frames, batch=args.batch)
         shard.gather(present=True)
 
     def fence():
@@ -143,14 +145,14 @@ def main():
         # of the dominant kernel (counts are deterministic, so they equal the timed launches')
         r.setCounting(True)
         r.resetCounters()
-        shard.render(frames)
+        shard.render(frames, batch=args.batch)
         r.sync()
         kc = r.getKernelCounters(1)
         r.setCounting(False)
-        n_launch = len(frames)
+        n_launch = (len(frames) + args.batch - 1) // args.batch   # path-trace launches per image
         owned_px = int(shard.owned_rows(HEIGHT).sum()) * WIDTH
         alg_bytes = (32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"] + 344.0 * kc["shaded_hits"]) / n_launch \
-            + (32.0 + 24.0) * owned_px  # accumulation read+write, G-buffer read
+            + (32.0 + 24.0 * min(args.batch, len(frames))) * owned_px  # accumulation read+write once per launch, G-buffer read per frame
         achieved = alg_bytes / (ktime["pathtrace_ms"] * 1e-3) / 1e9 if ktime["pathtrace_ms"] > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected by tools/make_profiles.sh,
         # N = 1 only; counters cannot be read from inside this process)
@@ -175,11 +177,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cornell box 1920x1080, 64 spp as 1 spp x 64 compute() dispatches, depth 8, "
-                                   "live-loop frame_count 1..64, one present() per image",
+            "config": {"workload": "cornell box 1920x1080, 64 spp as 1 spp x 64 compute() frames (frame_count 1..64, "
+                                   "issued as batched dispatches of %d frames), depth 8, one present() per image" % args.batch,
                        "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
                        "parallelism": "16-row stripes x %d ranks + 1 RCCL reduce/image" % world if world > 1 else "1 GPU",
-                       "rays_per_image": int(rays_total / args.steps)},
+                       "frames_per_dispatch": args.batch, "rays_per_image": int(rays_total / args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_pathtrace", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "avg_launch_ms": round(ktime["pathtrace_ms"], 4),

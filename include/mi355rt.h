@@ -95,6 +95,12 @@ int rt_recreate_bind_group(rt_ctx* ctx);
  * primary-visibility pass, path-trace pass.  Enqueues on the context stream. */
 int rt_compute(rt_ctx* ctx, uint32_t frame_count);
 
+/* n consecutive compute() calls as ONE dispatch of each kernel — the recorder's batch loop
+ * `for (k < batch) renderer.compute(samplesDone + k)` (VideoRecorder.ts:278-280, batch <= 50 there, <= 64 here).
+ * Host state (totalFrames, jitter) and every output are bit-identical to calling rt_compute n times; each frame keeps
+ * its own G-buffer (24 B/px extra per frame but the last). Needs the persistent kernel form (the default). */
+int rt_compute_batch(rt_ctx* ctx, const uint32_t* frame_counts, uint32_t n);
+
 /* present() — WebGPURenderer.ts:104-129: post pass -> render target, swap history. */
 int rt_present(rt_ctx* ctx);
 

@@ -237,3 +237,45 @@ def test_full_size_oracle_band(W, oracle_lib, gpu_renderer, scene, depth):
     pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
     rows = slice(band * 8, band * 8 + 8)
     assert np.array_equal(cpu.readAccum()[rows].view(np.uint32), acc[rows].view(np.uint32))
+
+
+@pytest.mark.parametrize("scene,w,h,depth,spp,frames,batch", [
+    ("cornell", 96, 72, 8, 1, tuple(range(1, 13)), 4),      # 3 batches of 4
+    ("cornell", 64, 48, 6, 2, (0, 1, 2, 3, 4), 5),          # recorder semantics (frame 0 and 1 overwrite), SPP 2
+    ("special", 80, 56, 8, 1, (1, 2, 3, 4, 5, 6, 7), 3),    # ragged last batch (3 + 3 + 1)
+    ("instanced1000", 64, 36, 8, 1, (1, 2, 3, 4), 4),       # global-memory kernel form
+    ("mixed", 64, 48, 10, 1, (1, 2, 3), 3),                 # thin lens
+])
+def test_batched_dispatch_equals_sequential_computes(W, oracle_lib, gpu_renderer, scene, w, h, depth, spp, frames, batch):
+    """rt_compute_batch == the same compute() calls one by one: accumulation, last frame's G-buffer, uniforms, counters."""
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, depth, spp, frames, present=False)
+    gpu_renderer.buildPipeline(depth, spp)
+    W.upload_scene(gpu_renderer, b, w, h)
+    gpu_renderer.setCounting(True)
+    gpu_renderer.resetCounters()
+    for i in range(0, len(frames), batch):
+        gpu_renderer.computeBatch(frames[i:i + batch])
+    gpu_renderer.sync()
+    pu.assert_parity(gpu_renderer, cpu, check_output=False)
+    gpu_renderer.present()
+    cpu.present()
+    pu.assert_parity(gpu_renderer, cpu, check_output=True, check_counters=False)
+
+
+def test_batched_dispatch_with_stripes(W, gpu_renderer):
+    b = pu.bridge_for(W, "cornell")
+    w, h, frames = 80, 72, tuple(range(1, 9))
+    pu.drive(gpu_renderer, W, b, w, h, 6, 1, frames, present=False)
+    full = gpu_renderer.readAccum()
+    total = np.zeros_like(full)
+    for rank in range(2):
+        r = W.WebGPURenderer(0)
+        r.setStripes(16, rank, 2)
+        r.buildPipeline(6, 1)
+        W.upload_scene(r, b, w, h)
+        r.computeBatch(frames)
+        total += r.readAccum()
+        r.destroy()
+    assert np.array_equal(total.view(np.uint32), full.view(np.uint32))

@@ -20,7 +20,8 @@ class Recording:
         self.calls = []
     def __getattr__(self, name):
         def f(*a):
-            self.calls.append((name,) + tuple(x for x in a if isinstance(x, (int, str))))
+            self.calls.append((name,) + tuple(list(x) if isinstance(x, range) else x
+                                              for x in a if isinstance(x, (int, str, range))))
             return False
         return f
 
@@ -40,8 +41,9 @@ def test_cadence_matches_the_reference_recorder(W):
     assert [c[1] for c in warm] == [0, 1, 2, 3, 4]
     rec.calls.clear()
     presents = loop.render_frame(64)
-    computes = [c[1] for c in rec.calls if c[0] == "compute"]
-    assert computes == list(range(64))              # frame_count = 0 .. N-1 (recorder semantics)
+    batches = [c[1] for c in rec.calls if c[0] == "computeBatch"]   # the batch loop is issued as batched dispatches
+    assert [f for bt in batches for f in bt] == list(range(64))    # frame_count = 0 .. N-1 (recorder semantics)
+    assert all(1 <= len(bt) <= 50 for bt in batches)
     assert presents == sum(1 for c in rec.calls if c[0] == "present") >= 1
     assert rec.calls[-2][0] == "present" and rec.calls[-1][0] == "sync"   # the finished batch always presents
     assert 1 <= loop.current_batch_size <= 50      # hard cap of 50 dispatches per batch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3 runs: N compute() dispatches of one scene at a given size, no torch.
-usage: prof_frames.py [scene] [width] [height] [frames] [depth] [variant] [detailed]"""
+usage: prof_frames.py [scene] [width] [height] [frames] [depth] [variant] [detailed] [ranks]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ frames = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 depth = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 variant = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 detailed = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+ranks = int(sys.argv[8]) if len(sys.argv) > 8 else 1   # render only rank 0 of N interleaved 16-row stripes
 
 b = W.WorldBridge()
 if scene == "viewer_diamond":
@@ -27,6 +28,8 @@ r = W.WebGPURenderer(0)
 r.buildPipeline(depth, 1)
 W.upload_scene(r, b, w, h)
 r.setKernelVariant(variant)
+if ranks > 1:
+    r.setStripes(16, 0, ranks)
 r.setCounting(bool(detailed))
 r.compute(1)
 r.sync()

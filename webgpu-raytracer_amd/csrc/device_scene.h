@@ -48,6 +48,17 @@ struct DevFrame {
   uint32_t own_run, own_period, own_first, own_tile_rows;
 };
 
+// One frame of a batched dispatch (rt_compute_batch): what changes from one compute() to the next.
+struct DevFrameSlot {
+  uint32_t frame_count;
+  float jitter_x, jitter_y;
+  uint32_t pad;
+  uint32_t* albedo;    // this frame's G-buffer planes
+  float4* normal_id;
+  float* depth;
+  uint64_t pad2;
+};
+
 struct DevPost {
   const float4* accum;
   const ushort4* history_in;  // rgba16f, previous frame

@@ -582,7 +582,18 @@ __global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __r
 
 // ================================================================ primary visibility
 template <bool DETAIL>
-__global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame F, rt_scene_uniforms U) {
+__global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame F, rt_scene_uniforms U,
+                                                           const DevFrameSlot* __restrict__ slots) {
+  // batched dispatch: blockIdx.y selects the frame; its jitter and G-buffer planes come from the slot table
+  if (slots) {
+    const DevFrameSlot sl = slots[blockIdx.y];
+    U.frame_count = sl.frame_count;
+    U.jitter[0] = sl.jitter_x;
+    U.jitter[1] = sl.jitter_y;
+    F.albedo = sl.albedo;
+    F.normal_id = sl.normal_id;
+    F.depth = sl.depth;
+  }
   uint32_t x, y;
   bool live = tile_pixel(U, x, y) && owns_row(F, y);
   LaneCounters c = {0, 0, 0, 0, 0, 0};
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame 
       F.depth[p_idx] = z_clip / z_view;
     }
   }
-  flush_counters<DETAIL>(c, F.counters, blockIdx.x);
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x + blockIdx.y * 977u);
 }
 
 // ======================================================================= path tracer
@@ -1118,7 +1129,12 @@ template <bool DETAIL, bool LDS>
 __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
                                                               uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
                                                               uint32_t n_tris_total, uint32_t n_inst_total,
-                                                              uint32_t n_verts_total) {
+                                                              uint32_t n_verts_total,
+                                                              const DevFrameSlot* __restrict__ slots, uint32_t n_slots) {
+  // Batched dispatch (rt_compute_batch): the launch covers n_slots consecutive compute() frames. A lane keeps its
+  // pixel for all n_slots x SPP samples and adds the frames into the accumulation value in frame order, so the
+  // result is bit-identical to n_slots separate dispatches while every launch carries n_slots times the work
+  // (this is what keeps the persistent waves fed when the image is sharded over several GPUs).
   extern __shared__ f4 s_scene[];
   // per-wave triangle work queue at the start of LDS, staged scene after it
   WaveWork WW;
@@ -1179,6 +1195,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   bool work_left = true;
 
   PathState p;
+  float4 acc_run = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // accumulation value of the lane's pixel across the batch
   bool alive = false;       // lane owns a running path
   bool have_pixel = false;  // lane owns a pixel whose samples are not all done
   uint32_t cnt_ext = 0, cnt_shadow = 0, cnt_nodes = 0, cnt_tris = 0, cnt_shaded = 0;
@@ -1232,7 +1249,9 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
     if (!alive && have_pixel) {
       const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
-      p.rng = init_rng(p.pixel, U.frame_count * F.spp + p.sample);
+      const uint32_t fslot = p.sample / F.spp;  // frame of the batch this sample belongs to
+      const DevFrameSlot slot = slots[fslot];
+      p.rng = init_rng(p.pixel, slot.frame_count * F.spp + (p.sample - fslot * F.spp));
       rt3 off = rt3_splat(0.0f);
       if (lens > 0.0f) {
         float r = rt_sqrt(rand_pcg(p.rng));
@@ -1244,8 +1263,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
         rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
         off = cu * rdk.x + cv * rdk.y;
       }
-      float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
-      float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+      float u = ((float)x + 0.5f + slot.jitter_x * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + slot.jitter_y * (float)U.height) / (float)U.height;
       p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
       p.ro = cam_o + off;
       p.throughput = rt3_splat(1.0f);
@@ -1254,11 +1273,11 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       p.specular = true;
       p.depth = 0u;
       // background pixel (or MAX_DEPTH = 0): the sample is black and ends at once
-      if (!(F.depth[p.pixel] >= 1.0f) && F.max_depth != 0u) {
-        float4 g = F.normal_id[p.pixel];
+      if (!(slot.depth[p.pixel] >= 1.0f) && F.max_depth != 0u) {
+        float4 g = slot.normal_id[p.pixel];
         p.tri = rt_f2u(g.z);
         p.inst = rt_f2u(g.w);
-        setup_surface(S, p, true, g.x, g.y, F.albedo[p.pixel]);
+        setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
         alive = true;
       }
     }
@@ -1416,15 +1435,21 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       alive = false;
       p.col = p.col + p.radiance;
       p.sample++;
-      if (p.sample >= F.spp) {
+      const uint32_t fdone = p.sample / F.spp;
+      if (fdone * F.spp == p.sample) {  // the last sample of frame (fdone - 1): Raytracer.wgsl:811-818
         rt3 c = p.col / (float)F.spp;
-        float4 acc = make_float4(c.x, c.y, c.z, 1.0f);
-        if (U.frame_count > 1u) {
-          float4 prev = F.accum[p.pixel];
-          acc = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
+        p.col = rt3_splat(0.0f);
+        const uint32_t fc = slots[fdone - 1u].frame_count;
+        if (fc > 1u) {
+          if (fdone == 1u) acc_run = F.accum[p.pixel];  // first frame of the batch continues the stored value
+          acc_run = make_float4(acc_run.x + c.x, acc_run.y + c.y, acc_run.z + c.z, acc_run.w + 1.0f);
+        } else {
+          acc_run = make_float4(c.x, c.y, c.z, 1.0f);
         }
-        F.accum[p.pixel] = acc;
-        have_pixel = false;
+        if (fdone >= n_slots) {
+          F.accum[p.pixel] = acc_run;
+          have_pixel = false;
+        }
       }
     }
     if (!work_left && __ballot(alive || have_pixel) == 0ull) break;

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,7 +67,11 @@ struct rt_ctx {
   uint32_t stripe_rows = 0, stripe_rank = 0, stripe_count = 1;
   int variant = 1;        // 1 = persistent waves + path regeneration (default), 0 = one-pixel-per-lane megakernel
   int num_cus = 256;      // multiProcessorCount of the device
+  int occ_blocks[4] = {0, 0, 0, 0};   // cached occupancy query per persistent-kernel variant
+  size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
+  DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
+  DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
 
   // kernel timing
   bool timing = false;
@@ -293,7 +298,8 @@ void rt_destroy(rt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->accum, &c->render_target,
-                         &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket};
+                         &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
+                         &c->slots, &c->gbuf_batch};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -463,19 +469,54 @@ int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32
 
 int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
 
-int rt_compute(rt_ctx* c, uint32_t frame_count) {
-  if (!c) return RT_ERR_INVALID;
-  c->total_frames++;
-  step_jitter(c, c->total_frames, frame_count);  // updateFrameUniforms(frameCount, totalFrames)
-  write_mixed(c, frame_count);
+// compute() for n consecutive frame counts in ONE dispatch of each kernel (n == 1: the plain compute()).
+static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
+  if (!c || !frame_counts || n == 0) return RT_ERR_INVALID;
+  // host state advances exactly as n successive compute() calls would (WebGPURenderer.ts:88-91)
+  std::vector<DevFrameSlot> slots(n);
+  for (uint32_t i = 0; i < n; i++) {
+    c->total_frames++;
+    step_jitter(c, c->total_frames, frame_counts[i]);  // updateFrameUniforms(frameCount, totalFrames)
+    write_mixed(c, frame_counts[i]);
+    slots[i].frame_count = frame_counts[i];
+    slots[i].jitter_x = c->uniforms.jitter[0];
+    slots[i].jitter_y = c->uniforms.jitter[1];
+    slots[i].pad = 0;
+    slots[i].pad2 = 0;
+  }
   if (!scene_ready(c)) return RT_SKIPPED;
   HIP_TRY(c, hipSetDevice(c->device));
   // Host-side shape checks before any kernel indexes these buffers.
   if (c->uniforms.light_count > c->n_lights)
     return fail(c, RT_ERR_INVALID, "light_count exceeds the uploaded lights buffer");
   if (c->blas_offset > c->n_nodes) return fail(c, RT_ERR_INVALID, "blas_base_idx exceeds the node buffer");
+  if (c->variant == 0 && n > 1) return fail(c, RT_ERR_INVALID, "batched dispatch needs the persistent kernel form");
   int r = prepare_scene(c);
   if (r < 0) return r;
+
+  const size_t npx = (size_t)c->width * c->height;
+  if (n > 1) {
+    r = ensure_buffer(c, c->gbuf_batch, (size_t)(n - 1) * npx * 24, false);
+    if (r < 0) return r;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    if (i + 1 == n) {  // the last frame lands in the main G-buffer, like a plain compute()
+      slots[i].albedo = (uint32_t*)c->render_target.ptr;
+      slots[i].normal_id = (float4*)c->g_normal.ptr;
+      slots[i].depth = (float*)c->g_depth.ptr;
+    } else {
+      char* base = (char*)c->gbuf_batch.ptr + (size_t)i * npx * 24;
+      slots[i].normal_id = (float4*)base;
+      slots[i].albedo = (uint32_t*)(base + npx * 16);
+      slots[i].depth = (float*)(base + npx * 20);
+    }
+  }
+  r = ensure_buffer(c, c->slots, (size_t)n * sizeof(DevFrameSlot), true);
+  if (r < 0) return r;
+  // pageable source: the runtime stages the bytes before returning, so `slots` may go out of scope
+  HIP_TRY(c, hipMemcpyAsync(c->slots.ptr, slots.data(), (size_t)n * sizeof(DevFrameSlot), hipMemcpyHostToDevice,
+                            c->stream));
+  const DevFrameSlot* dslots = (const DevFrameSlot*)c->slots.ptr;
 
   DevScene S = dev_scene(c);
   DevFrame F;
@@ -500,18 +541,19 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
       if ((ty / F.own_run) % c->stripe_count == c->stripe_rank) owned++;
     F.own_tile_rows = owned;
   }
-
   DevFrame Fp = F;  // the primary kernel counts into bank 0, the path tracer into bank 1
   F.counters = (uint64_t*)c->counters.ptr + (size_t)RT_COUNTER_SHARDS * 6;
   const uint32_t tiles = ((c->width + 7) / 8) * ((c->height + 7) / 8);
-  // 1. primary visibility (the reference clears + rasterises the G-buffer every compute())
+
+  // 1. primary visibility (the reference clears + rasterises the G-buffer every compute()); frame = blockIdx.y
   EventPair* ev = next_events(c, 0);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   if (c->detailed_counters)
-    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles), dim3(64), 0, c->stream, S, Fp, c->uniforms);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
   else
-    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles), dim3(64), 0, c->stream, S, Fp, c->uniforms);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+
   // 2. path trace
   if (c->variant == 0) {
     ev = next_events(c, 1);
@@ -527,23 +569,26 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
     const size_t lds_bytes = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
     const bool use_lds = lds_bytes + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
     const size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + (use_lds ? lds_bytes : 0);  // work queues + records
-    const void* fn;
-    if (use_lds)
-      fn = c->detailed_counters ? (const void*)rtk::k_pathtrace_persistent<true, true>
-                                : (const void*)rtk::k_pathtrace_persistent<false, true>;
-    else
-      fn = c->detailed_counters ? (const void*)rtk::k_pathtrace_persistent<true, false>
-                                : (const void*)rtk::k_pathtrace_persistent<false, false>;
-    int per_cu = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn));
-    if (per_cu < 1) per_cu = 1;
-    uint32_t blocks = (uint32_t)per_cu * (uint32_t)c->num_cus;
+    const int vi = (c->detailed_counters ? 2 : 0) + (use_lds ? 1 : 0);
+    static const void* const fns[4] = {(const void*)rtk::k_pathtrace_persistent<false, false>,
+                                       (const void*)rtk::k_pathtrace_persistent<false, true>,
+                                       (const void*)rtk::k_pathtrace_persistent<true, false>,
+                                       (const void*)rtk::k_pathtrace_persistent<true, true>};
+    const void* fn = fns[vi];
+    // resident workgroups per CU: queried once per (variant, LDS size)
+    if (c->occ_dyn[vi] != dyn || c->occ_blocks[vi] == 0) {
+      int per_cu = 0;
+      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn));
+      c->occ_blocks[vi] = per_cu < 1 ? 1 : per_cu;
+      c->occ_dyn[vi] = dyn;
+    }
+    uint32_t blocks = (uint32_t)c->occ_blocks[vi] * (uint32_t)c->num_cus;
     const uint32_t own_tiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;
     const uint32_t max_useful = (own_tiles + 3) / 4;  // one tile per wave at least
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
-    uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts;
-    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv};
+    uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts, ns = n;
+    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv, &dslots, &ns};
     ev = next_events(c, 1);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
@@ -551,6 +596,14 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
   }
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
+}
+
+int rt_compute(rt_ctx* c, uint32_t frame_count) { return compute_frames(c, &frame_count, 1); }
+
+int rt_compute_batch(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
+  if (!c) return RT_ERR_INVALID;
+  if (n > 64) return fail(c, RT_ERR_INVALID, "at most 64 frames per batch");
+  return compute_frames(c, frame_counts, n);
 }
 
 int rt_present(rt_ctx* c) {

@@ -31,10 +31,17 @@ class ShardedImage:
     def owned_rows(self, height):
         return (np.arange(height) // self.stripe_rows) % self.world == self.rank
 
-    def render(self, frames):
-        """Same per-frame call as the live loop, but present() is deferred to gather()."""
-        for f in frames:
-            self.r.compute(f)
+    def render(self, frames, batch=1):
+        """Same per-frame call as the live loop, but present() is deferred to gather(). batch > 1 issues the
+        frames as batched dispatches (rt_compute_batch, like the recorder's batch loop): bit-identical, and each
+        launch carries `batch` times the work, which is what keeps a GPU busy on 1/N of an image."""
+        frames = list(frames)
+        if batch > 1 and hasattr(self.r, "computeBatch"):
+            for i in range(0, len(frames), batch):
+                self.r.computeBatch(frames[i:i + batch])
+        else:
+            for f in frames:
+                self.r.compute(f)
 
     def gather(self, present=True):
         """Sum the per-rank accumulation buffers onto rank 0; rank 0 then runs the post pass."""

@@ -53,8 +53,11 @@ class FrameLoop:
         while samples_done < total_spp:
             batch = min(self.current_batch_size, total_spp - samples_done)
             t0 = self.clock()
-            for k in range(batch):
-                r.compute(samples_done + k)
+            if hasattr(r, "computeBatch"):   # one dispatch per kernel for the whole batch (bit-identical)
+                r.computeBatch(range(samples_done, samples_done + batch))
+            else:
+                for k in range(batch):
+                    r.compute(samples_done + k)
             samples_done += batch
             now = self.clock()
             finished = samples_done >= total_spp

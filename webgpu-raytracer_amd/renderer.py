@@ -43,6 +43,7 @@ def load_library(path=None):
         "rt_upload_bvh": (i32, [vp, vp, u32, vp, u32]),
         "rt_set_scene": (i32, [vp, vp, u32, u32]), "rt_recreate_bind_group": (i32, [vp]),
         "rt_compute": (i32, [vp, u32]), "rt_present": (i32, [vp]),
+        "rt_compute_batch": (i32, [vp, vp, u32]),
         "rt_capture": (i32, [vp, vp, ctypes.c_size_t]), "rt_sync": (i32, [vp]),
         "rt_read_accum": (i32, [vp, vp, ctypes.c_size_t]), "rt_write_accum": (i32, [vp, vp, ctypes.c_size_t]),
         "rt_read_gbuffer": (i32, [vp, vp, vp, vp]), "rt_read_history": (i32, [vp, vp, ctypes.c_size_t]),
@@ -67,7 +68,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     "rt_create rt_destroy rt_last_error rt_set_pipeline rt_resize rt_reset_accum rt_upload_textures rt_upload "
-    "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_present rt_capture "
+    "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_compute_batch rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
@@ -155,6 +156,11 @@ class WebGPURenderer:
 
     def compute(self, frameCount):
         return self._check(self.L.rt_compute(self.ctx, int(frameCount)), "compute")
+
+    def computeBatch(self, frameCounts):
+        """`for k in batch: compute(samplesDone + k)` (VideoRecorder.ts:278-280) as one dispatch per kernel."""
+        fc = np.ascontiguousarray(list(frameCounts), dtype=np.uint32)
+        return self._check(self.L.rt_compute_batch(self.ctx, _ptr(fc), fc.size), "computeBatch")
 
     def present(self):
         return self._check(self.L.rt_present(self.ctx), "present")
