@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3 runs: N compute() dispatches of one scene at a given size, no torch.
-usage: prof_frames.py [scene] [width] [height] [frames] [depth] [variant] [detailed] [ranks]"""
+usage: prof_frames.py [scene] [width] [height] [frames] [depth] [variant] [detailed] [ranks] [batch]"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ depth = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 variant = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 detailed = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 ranks = int(sys.argv[8]) if len(sys.argv) > 8 else 1   # render only rank 0 of N interleaved 16-row stripes
+batch = int(sys.argv[9]) if len(sys.argv) > 9 else 1   # frames per batched dispatch
 
 b = W.WorldBridge()
 if scene == "viewer_diamond":
@@ -37,8 +38,13 @@ r.resetCounters()
 r.setKernelTiming(True)
 r.kernelTimeMs()
 t0 = time.perf_counter()
-for f in range(2, frames + 2):
-    r.compute(f)
+fl = list(range(2, frames + 2))
+if batch > 1:
+    for i in range(0, len(fl), batch):
+        r.computeBatch(fl[i:i + batch])
+else:
+    for f in fl:
+        r.compute(f)
 r.sync()
 dt = time.perf_counter() - t0
 k = r.kernelTimeMs()

@@ -37,6 +37,7 @@ struct DevScene {
 
 struct DevFrame {
   float4* accum;        // W*H float4
+  float4* frame_col;    // batched dispatch only: n_slots x W*H frame colours (else nullptr)
   uint32_t* albedo;     // W*H rgba8 (render target: G-buffer albedo, later post output)
   float4* normal_id;    // W*H rgba32f
   float* depth;         // W*H f32

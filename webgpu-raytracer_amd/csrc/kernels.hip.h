@@ -595,7 +595,18 @@ __global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame 
     F.depth = sl.depth;
   }
   uint32_t x, y;
-  bool live = tile_pixel(U, x, y) && owns_row(F, y);
+  bool live;
+  if (F.own_period) {
+    // sharded render with tile-aligned stripes: blockIdx.x enumerates only the tiles of the rows this rank owns
+    const uint32_t tiles_x = (U.width + 7u) / 8u;
+    uint32_t trow = blockIdx.x / tiles_x;
+    trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
+    x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u);
+    y = trow * 8u + (threadIdx.x >> 3);
+    live = x < U.width && y < U.height;
+  } else {
+    live = tile_pixel(U, x, y) && owns_row(F, y);
+  }
   LaneCounters c = {0, 0, 0, 0, 0, 0};
   if (live) {
     const uint32_t p_idx = y * U.width + x;
@@ -1131,10 +1142,11 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
                                                               uint32_t n_tris_total, uint32_t n_inst_total,
                                                               uint32_t n_verts_total,
                                                               const DevFrameSlot* __restrict__ slots, uint32_t n_slots) {
-  // Batched dispatch (rt_compute_batch): the launch covers n_slots consecutive compute() frames. A lane keeps its
-  // pixel for all n_slots x SPP samples and adds the frames into the accumulation value in frame order, so the
-  // result is bit-identical to n_slots separate dispatches while every launch carries n_slots times the work
-  // (this is what keeps the persistent waves fed when the image is sharded over several GPUs).
+  // Batched dispatch (rt_compute_batch): the launch covers n_slots consecutive compute() frames. The work item is
+  // one (frame, pixel): tickets enumerate (frame, tile) pairs, so a launch has n_slots times as many tickets and the
+  // persistent waves stay fed and balanced even when a rank owns 1/8 of the image. With n_slots > 1 every item
+  // writes its frame colour to F.frame_col and k_accumulate_frames adds the frames in frame order afterwards, which
+  // makes the result bit-identical to n_slots separate dispatches; with n_slots == 1 the item accumulates directly.
   extern __shared__ f4 s_scene[];
   // per-wave triangle work queue at the start of LDS, staged scene after it
   WaveWork WW;
@@ -1195,7 +1207,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   bool work_left = true;
 
   PathState p;
-  float4 acc_run = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // accumulation value of the lane's pixel across the batch
+  uint32_t item_slot = 0u;  // frame of the batch the lane's current (frame, pixel) item belongs to
   bool alive = false;       // lane owns a running path
   bool have_pixel = false;  // lane owns a pixel whose samples are not all done
   uint32_t cnt_ext = 0, cnt_shadow = 0, cnt_nodes = 0, cnt_tris = 0, cnt_shaded = 0;
@@ -1219,11 +1231,11 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
           uint32_t t = 0;
           if (lane == (uint32_t)leader) t = atomicAdd(ticket, 1u);
           t = __shfl(t, leader, 64);
-          if (t >= n_tiles) {
+          if (t >= n_tiles * n_slots) {
             work_left = false;
             break;
           }
-          tile = t;
+          tile = t;  // frame-major ticket: frame = t / n_tiles, tile = t % n_tiles
           tile_pos = 0u;
         }
         // rank of this lane among the needy lanes
@@ -1231,15 +1243,17 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
             __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         const uint32_t slot = tile_pos + rank;
         if (need && slot < 64u) {
-          uint32_t trow = tile / tiles_x;
+          const uint32_t tile_in_frame = tile % n_tiles;
+          uint32_t trow = tile_in_frame / tiles_x;
           if (F.own_period) trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
-          const uint32_t x = (tile % tiles_x) * 8u + (slot & 7u);
+          const uint32_t x = (tile_in_frame % tiles_x) * 8u + (slot & 7u);
           const uint32_t y = trow * 8u + (slot >> 3);
           need = false;
           if (x < U.width && y < U.height && owns_row(F, y)) {
             have_pixel = true;
             p.pixel = y * U.width + x;
             p.sample = 0u;
+            item_slot = tile / n_tiles;
             p.col = rt3_splat(0.0f);
           }
         }
@@ -1249,9 +1263,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
     if (!alive && have_pixel) {
       const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
-      const uint32_t fslot = p.sample / F.spp;  // frame of the batch this sample belongs to
-      const DevFrameSlot slot = slots[fslot];
-      p.rng = init_rng(p.pixel, slot.frame_count * F.spp + (p.sample - fslot * F.spp));
+      const DevFrameSlot slot = slots[item_slot];
+      p.rng = init_rng(p.pixel, slot.frame_count * F.spp + p.sample);
       rt3 off = rt3_splat(0.0f);
       if (lens > 0.0f) {
         float r = rt_sqrt(rand_pcg(p.rng));
@@ -1435,21 +1448,20 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       alive = false;
       p.col = p.col + p.radiance;
       p.sample++;
-      const uint32_t fdone = p.sample / F.spp;
-      if (fdone * F.spp == p.sample) {  // the last sample of frame (fdone - 1): Raytracer.wgsl:811-818
+      if (p.sample >= F.spp) {  // the item's last sample: Raytracer.wgsl:811-818
         rt3 c = p.col / (float)F.spp;
-        p.col = rt3_splat(0.0f);
-        const uint32_t fc = slots[fdone - 1u].frame_count;
-        if (fc > 1u) {
-          if (fdone == 1u) acc_run = F.accum[p.pixel];  // first frame of the batch continues the stored value
-          acc_run = make_float4(acc_run.x + c.x, acc_run.y + c.y, acc_run.z + c.z, acc_run.w + 1.0f);
+        if (F.frame_col) {
+          // batched: park the frame colour; k_accumulate_frames adds the frames in order
+          F.frame_col[(size_t)item_slot * ((size_t)U.width * U.height) + p.pixel] = make_float4(c.x, c.y, c.z, 1.0f);
         } else {
-          acc_run = make_float4(c.x, c.y, c.z, 1.0f);
+          float4 acc = make_float4(c.x, c.y, c.z, 1.0f);
+          if (slots[0].frame_count > 1u) {
+            float4 prev = F.accum[p.pixel];
+            acc = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
+          }
+          F.accum[p.pixel] = acc;
         }
-        if (fdone >= n_slots) {
-          F.accum[p.pixel] = acc_run;
-          have_pixel = false;
-        }
+        have_pixel = false;
       }
     }
     if (!work_left && __ballot(alive || have_pixel) == 0ull) break;
@@ -1464,6 +1476,24 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   c.tris = cnt_tris;
   c.shaded = cnt_shaded;
   flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
+// Ordered accumulation of a batched dispatch: acc = (frame_count > 1 ? acc : 0) + (col_f, 1) for f = 0..n-1, the
+// exact sequence of f32 additions n separate dispatches perform (Raytracer.wgsl:813-818).
+__global__ __launch_bounds__(256) void k_accumulate_frames(DevFrame F, const DevFrameSlot* __restrict__ slots,
+                                                           uint32_t n_slots, uint32_t width, uint32_t height) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t npx = width * height;
+  if (p >= npx || !owns_row(F, p / width)) return;
+  float4 acc = F.accum[p];
+  for (uint32_t f = 0; f < n_slots; f++) {
+    const float4 c = F.frame_col[(size_t)f * npx + p];
+    if (slots[f].frame_count > 1u)
+      acc = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, acc.w + 1.0f);
+    else
+      acc = make_float4(c.x, c.y, c.z, 1.0f);
+  }
+  F.accum[p] = acc;
 }
 
 // ===================================================================== post process

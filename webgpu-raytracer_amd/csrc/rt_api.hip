@@ -72,6 +72,7 @@ struct rt_ctx {
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
+  DeviceBuffer frame_col;   // per-frame colours of a batch, added in frame order by k_accumulate_frames
 
   // kernel timing
   bool timing = false;
@@ -299,7 +300,7 @@ void rt_destroy(rt_ctx* c) {
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
-                         &c->slots, &c->gbuf_batch};
+                         &c->slots, &c->gbuf_batch, &c->frame_col};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -498,6 +499,8 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   if (n > 1) {
     r = ensure_buffer(c, c->gbuf_batch, (size_t)(n - 1) * npx * 24, false);
     if (r < 0) return r;
+    r = ensure_buffer(c, c->frame_col, (size_t)n * npx * 16, false);
+    if (r < 0) return r;
   }
   for (uint32_t i = 0; i < n; i++) {
     if (i + 1 == n) {  // the last frame lands in the main G-buffer, like a plain compute()
@@ -521,6 +524,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   DevScene S = dev_scene(c);
   DevFrame F;
   F.accum = accum_ptr(c);
+  F.frame_col = n > 1 ? (float4*)c->frame_col.ptr : nullptr;
   F.albedo = (uint32_t*)c->render_target.ptr;
   F.normal_id = (float4*)c->g_normal.ptr;
   F.depth = (float*)c->g_depth.ptr;
@@ -544,14 +548,15 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   DevFrame Fp = F;  // the primary kernel counts into bank 0, the path tracer into bank 1
   F.counters = (uint64_t*)c->counters.ptr + (size_t)RT_COUNTER_SHARDS * 6;
   const uint32_t tiles = ((c->width + 7) / 8) * ((c->height + 7) / 8);
+  const uint32_t ptiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;  // primary kernel grid
 
   // 1. primary visibility (the reference clears + rasterises the G-buffer every compute()); frame = blockIdx.y
   EventPair* ev = next_events(c, 0);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   if (c->detailed_counters)
-    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(tiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
   else
-    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(tiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
+    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
 
   // 2. path trace
@@ -584,7 +589,15 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     }
     uint32_t blocks = (uint32_t)c->occ_blocks[vi] * (uint32_t)c->num_cus;
     const uint32_t own_tiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;
-    const uint32_t max_useful = (own_tiles + 3) / 4;  // one tile per wave at least
+    // tiles per wave: 1 = as many waves as there are tiles (up to the resident limit); larger values launch fewer
+    // waves so that each can regenerate lanes from several tiles (only pays when a launch carries many frames)
+    static const uint32_t tiles_per_wave_env = []() {
+      const char* e = getenv("RT_TILES_PER_WAVE");
+      int v = e ? atoi(e) : 0;
+      return (uint32_t)(v < 0 ? 0 : v);
+    }();
+    const uint32_t tiles_per_wave = tiles_per_wave_env ? tiles_per_wave_env : 1u;
+    const uint32_t max_useful = (own_tiles * n + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);  // tickets = tiles x frames
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
     uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts, ns = n;
@@ -593,6 +606,9 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
     if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+    if (n > 1)  // ordered accumulation of the batch's frame colours
+      hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots,
+                         n, c->width, c->height);
   }
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
