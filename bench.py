@@ -161,7 +161,10 @@ def main():
         if world == 1 and os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
+                # the PMC passes were taken at 32 frames per launch; scale to this run's batch size
                 traffic = pmc.get("k_pathtrace_bytes_per_launch")
+                if traffic is not None and pmc.get("frames_per_launch"):
+                    traffic = traffic * min(args.batch, len(frames)) / pmc["frames_per_launch"]
             except Exception:
                 traffic, pmc = None, {}
         out = {

@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command itself
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/bench_trace/*/*_kernel_stats.csv $OUT/r01_bench_kernel_stats.csv
-# 2. PMC passes on 8 dispatches of the same workload (counters in their own runs)
+# 2. PMC passes on the same workload: 64 frames as two batched dispatches of 32 (counters in their own runs)
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $set | tr ' ' '+' | cut -c1-60)
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 $R/tools/prof_frames.py cornell 1920 1080 8 8 1 0 > $OUT/pmc_$name.log 2>&1 || echo "pass failed: $set"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 $R/tools/prof_frames.py cornell 1920 1080 64 8 1 0 1 32 > $OUT/pmc_$name.log 2>&1 || echo "pass failed: $set"
   python3 $R/tools/pmc_summary.py $OUT/pmc_$name >> $OUT/r01_pmc_summary.txt
 done
 # 3. the post pass too (FETCH/WRITE calibration on a streaming kernel)
