@@ -45,8 +45,9 @@ def test_addon_loads_and_world_arrays_match_python(W, addon):
 @needs_node
 @pytest.mark.gpu
 def test_javascript_driven_render_matches_the_oracle(W, oracle_lib, addon):
+    env = dict(os.environ, RT_NODE_BATCH="4")   # 3 live-loop frames, then frames 4..7 through computeBatch + present
     out = subprocess.run([node, os.path.join(NODE_DIR, "render_cornell.js"), "cornell", "96", "80", "3", "4"],
-                         check=True, capture_output=True, text=True, timeout=300).stdout
+                         check=True, capture_output=True, text=True, timeout=300, env=env).stdout
     got = json.loads(out.strip().splitlines()[-1])
     b = W.WorldBridge()
     b.loadScene("cornell")
@@ -56,6 +57,9 @@ def test_javascript_driven_render_matches_the_oracle(W, oracle_lib, addon):
     for f in (1, 2, 3):
         cpu.compute(f)
         cpu.present()
+    for f in (4, 5, 6, 7):
+        cpu.compute(f)
+    cpu.present()
     assert hashlib.sha256(cpu.readAccum().tobytes()).hexdigest() == got["accum_sha256"]
     assert hashlib.sha256(cpu.captureFrame()["data"].tobytes()).hexdigest() == got["rgba_sha256"]
     c = cpu.getCounters()

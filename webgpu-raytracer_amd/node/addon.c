@@ -165,6 +165,13 @@ static napi_value rtCompute(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 2, a)) return NULL;
   return make_int(env, rt_compute((rt_ctx*)get_ptr(env, a[0]), get_u32(env, a[1])));
 }
+static napi_value rtComputeBatch(napi_env env, napi_callback_info info) { /* Uint32Array of frame counts */
+  napi_value a[2];
+  void* p;
+  size_t n;
+  if (!get_args(env, info, 2, a) || !get_bytes(env, a[1], &p, &n)) return NULL;
+  return make_int(env, rt_compute_batch((rt_ctx*)get_ptr(env, a[0]), (const uint32_t*)p, (uint32_t)(n / 4)));
+}
 static napi_value rtPresent(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -313,6 +320,7 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"rtSetPipeline", rtSetPipeline}, {"rtResize", rtResize}, {"rtResetAccum", rtResetAccum},
                {"rtUploadTextures", rtUploadTextures}, {"rtUpload", rtUpload}, {"rtUploadGeometry", rtUploadGeometry},
                {"rtUploadBVH", rtUploadBVH}, {"rtSetScene", rtSetScene}, {"rtCompute", rtCompute},
+               {"rtComputeBatch", rtComputeBatch},
                {"rtPresent", rtPresent}, {"rtSync", rtSync}, {"rtCapture", rtCapture}, {"rtReadAccum", rtReadAccum},
                {"rtGetCounters", rtGetCounters}, {"msCreate", msCreate}, {"msDestroy", msDestroy},
                {"msUpdate", msUpdate}, {"msUpdateCamera", msUpdateCamera}, {"msGet", msGet},

@@ -14,6 +14,7 @@ export class WebGPURenderer {
   updateSceneUniforms(cameraData: Float32Array, frameCount: number, lightCount: number): void;
   recreateBindGroup(): void;
   compute(frameCount: number): void;
+  computeBatch(frameCounts: ArrayLike<number>): void;
   present(): void;
   captureFrame(): Promise<{ data: ArrayBufferLike; width: number; height: number }>;
   readAccum(): Float32Array;

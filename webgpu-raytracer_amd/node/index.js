@@ -59,6 +59,8 @@ class WebGPURenderer {
   }
   recreateBindGroup() {}
   compute(frameCount) { this._check(native.rtCompute(this._ctx, frameCount), 'compute'); }
+  // the recorder's `for (k < batch) compute(samplesDone + k)` as one dispatch per kernel (bit-identical)
+  computeBatch(frameCounts) { this._check(native.rtComputeBatch(this._ctx, Uint32Array.from(frameCounts)), 'computeBatch'); }
   present() { this._check(native.rtPresent(this._ctx), 'present'); }
   async captureFrame() {
     if (!this.width) throw new Error('No render target');

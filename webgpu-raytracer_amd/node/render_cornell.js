@@ -27,6 +27,11 @@ const { WebGPURenderer, WorldBridge } = require('./index.js');
   renderer.recreateBindGroup();
   renderer.resetAccumulation();
   for (let f = 1; f <= parseInt(frames, 10); f++) { renderer.compute(f); renderer.present(); }
+  if (process.env.RT_NODE_BATCH) {  // extra frames through the batched entry point
+    const n = parseInt(process.env.RT_NODE_BATCH, 10), first = parseInt(frames, 10) + 1;
+    renderer.computeBatch(Array.from({ length: n }, (_, i) => first + i));
+    renderer.present();
+  }
   await renderer.device.queue.onSubmittedWorkDone();
   const frame = await renderer.captureFrame();
   const acc = renderer.readAccum();
