@@ -43,8 +43,9 @@ for name, scene, w, h, frames, depth, div in CONFIGS:
     W.upload_scene(g2, b, w, h)
     g2.resetCounters()
     t0 = time.perf_counter()
-    for f in fr:
-        g2.compute(f)
+    B = 32 if w * h <= 1920 * 1080 else 8      # frames per batched dispatch (one G-buffer per frame in flight)
+    for i in range(0, len(fr), B):
+        g2.computeBatch(fr[i:i + B])
     g2.present()
     g2.sync()
     dt = time.perf_counter() - t0
