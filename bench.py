@@ -66,6 +66,7 @@ def main():
     import webgpu_raytracer_amd as pkg
     from webgpu_raytracer_amd import distributed as rtdist
 
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,6 +94,12 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    # in-tree libraries: built by local rank 0 if missing or stale (a no-op otherwise), the others wait
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        pkg._build.build_scene()
+        pkg._build.build_rt()
+    if world > 1 or force_dist:
+        dist.barrier()
     bridge = pkg.WorldBridge()
     bridge.loadScene(SCENE)
     r = pkg.WebGPURenderer(local_rank)

@@ -49,8 +49,12 @@ class ShardedImage:
             import torch
             import torch.distributed as dist
             if self.device_tensor is not None:
-                # kernels were enqueued on torch's current stream (setStream), so the collective is ordered after them
+                # Explicit fences on both sides of the collective: the renderer may run on its own HIP stream
+                # (torch's default stream has handle 0, which rt_set_stream reads as "own stream"), and RCCL orders
+                # itself only against torch's current stream. Two host syncs per image, ~20 us each.
+                self.r.sync()
                 dist.reduce(self.device_tensor, dst=0, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize(self.device_tensor.device)
             else:
                 self.r.sync()
                 t = torch.from_numpy(self.r.readAccum())
