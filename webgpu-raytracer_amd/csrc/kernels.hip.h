@@ -873,21 +873,6 @@ __device__ __forceinline__ bool hit_box4(f4 lo, f4 hi, const LocalRay& r, float 
   float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
   return tm_near <= tm_far;
 }
-__device__ __forceinline__ float hit_tri4(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max) {
-  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
-  rt3 h = rt_cross(r.d, e2);
-  float a = rt_dot(e1, h);
-  if (rt_abs(a) < 1e-6f) return -1.0f;
-  float f = 1.0f / a;
-  rt3 s = r.o - v0;
-  float u = f * rt_dot(s, h);
-  if (u < 0.0f || u > 1.0f) return -1.0f;
-  rt3 q = rt_cross(s, e1);
-  float v = f * rt_dot(r.d, q);
-  if (v < 0.0f || u + v > 1.0f) return -1.0f;
-  float t = f * rt_dot(e2, q);
-  return (t > t_min && t < t_max) ? t : -1.0f;
-}
 __device__ __forceinline__ LocalRay to_instance(const TravMem& M, uint32_t inst, rt3 o, rt3 d, uint32_t& blas_off) {
   f4 r0 = M.inst_trav[4 * inst + 0], r1 = M.inst_trav[4 * inst + 1], r2 = M.inst_trav[4 * inst + 2];
   blas_off = rt_f2u(M.inst_trav[4 * inst + 3].x);
