@@ -10,6 +10,8 @@
 //              80-B topology row + 3 dependent 16-B position gathers, Raytracer.wgsl:476-477)
 //   inst_trav  4 x float4 / inst   rows 0..2 of the inverse matrix (so M*p is 3 dot-like rows),
 //              {blas_node_offset, inv[3], inv[7], inv[11]}                    (64 B instead of 144 B)
+//   light_rec  4 x float4 / light  world-space light triangle, its unit normal and area (what sample_light_source
+//              recomputes per NEE sample from topology + positions + instance matrix, Raytracer.wgsl:354-373)
 //   topo/pos/nrm/uv/inst/lights    raw arrays, read once per shaded hit
 #ifndef MI355RT_DEVICE_SCENE_H
 #define MI355RT_DEVICE_SCENE_H
@@ -30,6 +32,7 @@ struct DevScene {
   const float2* uv;         // 1 per vertex
   const float4* inst;       // 9 per instance (raw Instance)
   const uint2* lights;      // LightRef
+  const float4* light_rec;  // 4 per light: {v0.xyz, area} {v1.xyz, n.x} {v2.xyz, n.y} {n.z, tri, 0, 0} in world space
   const uint8_t* tex;       // layers x 1024 x 1024 x 4, or nullptr => 1x1 white default
   uint32_t tex_layers;
   uint32_t n_lights;        // elements in `lights` (for the robust-access clamp)

@@ -458,8 +458,18 @@ __device__ LightSample sample_light(const DevScene& S, uint32_t light_count, rt3
   if (light_count == 0u) return none;
   uint32_t pick = rt_f2u32_sat(rand_pcg(rng) * (float)light_count);
   if (pick >= S.n_lights) pick = S.n_lights - 1u;  // robust buffer access clamp (rand can be exactly 1.0)
-  uint2 ref = S.lights[pick];
-  WorldTri w = world_triangle(S, ref.y, ref.x);
+  // world-space triangle, unit normal and area of the picked light: precomputed per light at upload time
+  // (k_prepare_lights, same operations as Raytracer.wgsl:354-373, so bit-identical)
+  const float4 q0 = S.light_rec[4 * pick], q1 = S.light_rec[4 * pick + 1], q2 = S.light_rec[4 * pick + 2],
+               q3 = S.light_rec[4 * pick + 3];
+  WorldTri w;
+  w.v0 = xyz(q0);
+  w.v1 = xyz(q1);
+  w.v2 = xyz(q2);
+  const rt3 n_raw = rt3_make(q1.w, q2.w, q3.x);
+  const float area = q0.w;
+  uint2 ref;
+  ref.y = rt_f2u(q3.y);
   float r1 = rand_pcg(rng);
   float r2 = rand_pcg(rng);
   float sqrt_r1 = rt_sqrt(r1);
@@ -467,11 +477,6 @@ __device__ LightSample sample_light(const DevScene& S, uint32_t light_count, rt3
   float v = r2 * sqrt_r1;
   float ww = 1.0f - u - v;
   rt3 p = w.v0 * u + w.v1 * v + w.v2 * ww;
-  rt3 edge1 = w.v1 - w.v0;
-  rt3 edge2 = w.v2 - w.v0;
-  rt3 cr = rt_cross(edge1, edge2);
-  rt3 n_raw = rt_normalize(cr);
-  float area = rt_length(cr) * 0.5f;
   rt3 l_dir = p - hit_p;
   float dist_sq = rt_dot(l_dir, l_dir);
   float dist = rt_sqrt(dist_sq);
@@ -568,6 +573,24 @@ __global__ void k_prepare_tris(const float4* __restrict__ topo, const float4* __
   tri_geom[3 * i + 0] = make_float4(v0.x, v0.y, v0.z, 0.0f);
   tri_geom[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
   tri_geom[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+}
+__global__ void k_prepare_lights(DevScene S, float4* __restrict__ light_rec, uint32_t n, uint32_t n_tris,
+                                 uint32_t n_inst) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint2 ref = S.lights[i];
+  if (ref.y >= n_tris) ref.y = n_tris - 1;  // robust buffer access: clamp instead of faulting
+  if (ref.x >= n_inst) ref.x = n_inst - 1;
+  WorldTri w = world_triangle(S, ref.y, ref.x);
+  rt3 edge1 = w.v1 - w.v0;
+  rt3 edge2 = w.v2 - w.v0;
+  rt3 cr = rt_cross(edge1, edge2);
+  rt3 n_raw = rt_normalize(cr);
+  float area = rt_length(cr) * 0.5f;
+  light_rec[4 * i + 0] = make_float4(w.v0.x, w.v0.y, w.v0.z, area);
+  light_rec[4 * i + 1] = make_float4(w.v1.x, w.v1.y, w.v1.z, n_raw.x);
+  light_rec[4 * i + 2] = make_float4(w.v2.x, w.v2.y, w.v2.z, n_raw.y);
+  light_rec[4 * i + 3] = make_float4(n_raw.z, rt_u2f(ref.y), 0.0f, 0.0f);
 }
 __global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __restrict__ inst_trav, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1116,7 +1139,7 @@ __device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, b
 __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
                                                   uint32_t n_lights) {
   return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)2 * n_verts +
-         ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2;
+         ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
 }
 
 // Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
@@ -1164,6 +1187,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));
     S.inst = reinterpret_cast<const float4*>(stage(Sg.inst, (size_t)9 * n_inst_total));
     S.lights = reinterpret_cast<const uint2*>(stage(Sg.lights, ((size_t)Sg.n_lights + 1) / 2));
+    S.light_rec = reinterpret_cast<const float4*>(stage(Sg.light_rec, (size_t)4 * Sg.n_lights));
     __syncthreads();
     M.nodes = ln;
     M.tri_geom = lt;

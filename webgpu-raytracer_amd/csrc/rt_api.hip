@@ -44,8 +44,8 @@ struct rt_ctx {
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures;
   // derived buffers (device_scene.h)
-  DeviceBuffer tri_geom, inst_trav;
-  bool tris_dirty = true, inst_dirty = true;
+  DeviceBuffer tri_geom, inst_trav, light_rec;
+  bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
   uint32_t n_tris = 0, n_instances = 0, n_lights = 0, n_verts = 0, n_nodes = 0, tex_layers = 0;
   std::vector<uint32_t> draw_commands_host;  // kept like ResourceManager.drawCommandsArray
 
@@ -180,6 +180,8 @@ void write_mixed(rt_ctx* c, uint32_t frame_count) {  // the 48 bytes at offset 1
 
 float4* accum_ptr(rt_ctx* c) { return (float4*)(c->external_accum ? c->external_accum : c->accum.ptr); }
 
+DevScene dev_scene(const rt_ctx* c);
+
 int prepare_scene(rt_ctx* c) {
   if (c->tris_dirty && c->n_tris && c->n_verts) {
     int r = ensure_buffer(c, c->tri_geom, (size_t)c->n_tris * 48, true);
@@ -197,6 +199,15 @@ int prepare_scene(rt_ctx* c) {
                        (const float4*)c->instances.ptr, (float4*)c->inst_trav.ptr, c->n_instances);
     HIP_TRY(c, hipGetLastError());
     c->inst_dirty = false;
+  }
+  if (c->lights_dirty && c->n_lights && c->n_tris && c->n_instances && c->n_verts) {
+    int r = ensure_buffer(c, c->light_rec, (size_t)c->n_lights * 64, true);
+    if (r < 0) return r;
+    DevScene S = dev_scene(c);
+    hipLaunchKernelGGL(rtk::k_prepare_lights, dim3((c->n_lights + 255) / 256), dim3(256), 0, c->stream, S,
+                       (float4*)c->light_rec.ptr, c->n_lights, c->n_tris, c->n_instances);
+    HIP_TRY(c, hipGetLastError());
+    c->lights_dirty = false;
   }
   return RT_OK;
 }
@@ -219,6 +230,7 @@ DevScene dev_scene(const rt_ctx* c) {
   s.uv = (const float2*)c->uv.ptr;
   s.inst = (const float4*)c->instances.ptr;
   s.lights = (const uint2*)c->lights.ptr;
+  s.light_rec = (const float4*)c->light_rec.ptr;
   s.tex = c->tex_layers ? (const uint8_t*)c->textures.ptr : nullptr;
   s.tex_layers = c->tex_layers;
   s.n_lights = c->n_lights;
@@ -298,7 +310,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
-                         &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->accum, &c->render_target,
+                         &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col};
   for (DeviceBuffer* b : all) free_buffer(*b);
@@ -387,6 +399,7 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       if (r < 0) return r;
       c->n_tris = (uint32_t)(bytes / sizeof(rt_topology));
       c->tris_dirty = true;
+      c->lights_dirty = true;
       return r;
     case RT_KIND_INSTANCE:
       if (bytes % sizeof(rt_instance)) return fail(c, RT_ERR_INVALID, "instances must be 144 bytes each");
@@ -394,12 +407,14 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       if (r < 0) return r;
       c->n_instances = (uint32_t)(bytes / sizeof(rt_instance));
       c->inst_dirty = true;
+      c->lights_dirty = true;
       return r;
     case RT_KIND_LIGHTS:
       if (bytes % sizeof(rt_light_ref)) return fail(c, RT_ERR_INVALID, "lights must be 8 bytes each");
       r = upload(c, c->lights, data, bytes);
       if (r < 0) return r;
       c->n_lights = (uint32_t)(bytes / sizeof(rt_light_ref));
+      c->lights_dirty = true;
       return r;
     case RT_KIND_DRAW_COMMANDS: {
       // not on the 1.5x policy in the reference (ResourceManager.ts:264-278); kept on the host too
@@ -436,6 +451,7 @@ int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const fl
   c->n_verts = vertex_count;
   c->vertex_count = vertex_count;
   c->tris_dirty = true;
+  c->lights_dirty = true;
   return (r0 | r1 | r2) ? RT_REALLOCATED : RT_OK;
 }
 
