@@ -200,7 +200,8 @@ def main():
                          "note": "algorithmic gather bytes (SURVEY 8d) are served by LDS/L1, so achieved can exceed the HBM "
                                  "peak; the kernel is VALU-issue bound",
                          "valu_busy_frac": pmc.get("valu_busy_frac"),
-                         "valu_lane_utilization": pmc.get("valu_lane_utilization")},
+                         "valu_lane_utilization": pmc.get("valu_lane_utilization"),
+                         "valu": pmc.get("valu")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, bridge, frames)
