@@ -279,3 +279,36 @@ def test_batched_dispatch_with_stripes(W, gpu_renderer):
         total += r.readAccum()
         r.destroy()
     assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene,w,h,depth,frames,batch", [
+    ("cornell", 96, 72, 8, (1, 2, 3, 4), 1),
+    ("cornell", 64, 48, 6, (0, 1, 2, 3, 4, 5), 3),
+    ("special", 80, 56, 8, (1, 2, 3), 3),
+    ("mixed", 64, 48, 10, (1, 2), 2),
+    ("instanced1000", 96, 54, 8, (1, 2, 3, 4), 2),
+    ("sponza_like", 64, 36, 8, (1, 2), 2),
+    ("glass_blob", 48, 27, 16, (1, 2), 1),
+    ("cornell", 33, 21, 1, (1, 2), 2),                      # MAX_DEPTH = 1: no extension rays at all
+])
+def test_wavefront_form_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, frames, batch):
+    """Kernel variant 2 (shade / trace stages with the path state in HBM) against the oracle: accumulation, G-buffer,
+    uniforms and all six counters; then present()."""
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
+    gpu_renderer.setKernelVariant(2)
+    gpu_renderer.buildPipeline(depth, 1)
+    W.upload_scene(gpu_renderer, b, w, h)
+    gpu_renderer.setCounting(True)
+    gpu_renderer.resetCounters()
+    for i in range(0, len(frames), batch):
+        if batch == 1:
+            gpu_renderer.compute(frames[i])
+        else:
+            gpu_renderer.computeBatch(frames[i:i + batch])
+    gpu_renderer.sync()
+    pu.assert_parity(gpu_renderer, cpu, check_output=False)
+    gpu_renderer.present()
+    cpu.present()
+    pu.assert_parity(gpu_renderer, cpu, check_output=True, check_counters=False)

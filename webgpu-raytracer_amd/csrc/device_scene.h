@@ -63,6 +63,26 @@ struct DevFrameSlot {
   uint64_t pad2;
 };
 
+// Wavefront form (large scenes): path state lives in HBM between the shade and trace stages.
+struct WfState {      // SoA planes, one element per (frame, pixel) item
+  float4* a;          // ro.xyz, hit_t
+  float4* b;          // rd.xyz, prev_bsdf_pdf
+  float4* c;          // throughput.xyz, bitcast(rng)
+  float4* d;          // radiance.xyz, bitcast(flags): depth | specular << 8 | ended << 9 | nee_valid << 10
+  float4* e;          // pending NEE term .xyz, bitcast(tri)
+  uint32_t* inst;
+};
+struct WfQueues {
+  uint32_t* active[2];    // path ids alive at the current / next depth
+  uint32_t* shadow_ids;   // shadow-ray queue: path id ...
+  float4* shadow_rays;    // ... and {o.xyz, t_max} {d.xyz, 0}
+  uint32_t* ext_ids;      // extension-ray queue (the ray is the path's ro / rd)
+  uint32_t* counters;     // 8 u32 per depth: n_active, n_shadow, n_ext, head_shadow, head_ext, 0, 0, 0
+};
+#define WF_FLAG_SPECULAR 0x100u
+#define WF_FLAG_ENDED 0x200u
+#define WF_FLAG_NEE_VALID 0x400u
+
 struct DevPost {
   const float4* accum;
   const ushort4* history_in;  // rgba16f, previous frame

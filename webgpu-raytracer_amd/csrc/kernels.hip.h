@@ -1135,6 +1135,113 @@ __device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, b
   p.geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
 }
 
+// One bounce of ray_color for a path whose surface frame is ready (Raytracer.wgsl:656-728): emissive / MIS, the
+// three NEE draws and the pending NEE term, BSDF sampling, throughput, ray offset, Russian roulette, depth limit.
+// The shadow ray and the extension ray it asks for are traced by the caller (megakernel trip or wavefront stage).
+struct BounceOut {
+  bool want_shadow, want_extend, nee_valid, ended;
+  rt3 sh_o, sh_d, nee;
+  float sh_tmax;
+};
+__device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_count, uint32_t max_depth, PathState& p,
+                                             BounceOut& o) {
+  o.want_shadow = o.want_extend = o.nee_valid = false;
+  o.sh_o = o.sh_d = o.nee = rt3_splat(0.0f);
+  o.sh_tmax = 0.0f;
+  float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
+  const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
+  const rt3 hit_p = p.ro + p.rd * p.hit_t;
+  p.normal = (rt_dot(p.rd, p.normal) < 0.0f) ? p.normal : -p.normal;
+  p.geom_n = (rt_dot(p.rd, p.geom_n) < 0.0f) ? p.geom_n : -p.geom_n;
+  float metallic = d1.x, roughness = d1.y;
+  if (d2.y > -0.5f) {
+    rt3 mr = sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.y));
+    metallic *= mr.z;
+    roughness *= mr.y;
+  }
+  roughness = rt_max(roughness, 0.005f);
+  rt3 emissive = xyz(d3);
+  if (d2.w > -0.5f) emissive = emissive * sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.w));
+  const rt3 f0 = rt_mix3(rt3_splat(0.04f), p.albedo, metallic);
+
+  bool ended = false;
+  if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
+    rt3 em_val = (mat_type == 3u) ? p.albedo : emissive;
+    if (p.specular) {
+      p.radiance = p.radiance + p.throughput * em_val;
+    } else {
+      p.radiance = p.radiance + p.throughput * em_val *
+                                    power_heuristic(p.prev_pdf, light_pdf(S, light_count, p.tri, p.inst, p.hit_t, p.rd));
+    }
+    if (mat_type == 3u) ended = true;
+  }
+  if (!ended) {
+    if (mat_type != 2u) {  // NEE: the 3 draws happen here, the shadow ray is traced below
+      LightSample ls = sample_light(S, light_count, hit_p, p.rng);
+      if (ls.pdf > 0.0f) {
+        rt3 bsdf_val = rt3_splat(0.0f);
+        float bsdf_pdf = 0.0f;
+        if (mat_type == 0u) {
+          bsdf_val = p.albedo / RT_PI;
+          bsdf_pdf = rt_max(rt_dot(p.normal, ls.dir), 0.0f) / RT_PI;
+        } else if (mat_type == 1u) {
+          bsdf_val = eval_ggx(p.normal, -p.rd, ls.dir, roughness, f0);
+          rt3 H = rt_normalize(-p.rd + ls.dir);
+          bsdf_pdf = (ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f)) /
+                     (4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
+        }
+        o.want_shadow = true;  // the reference traces the shadow ray before looking at bsdf_pdf
+        o.sh_o = hit_p + p.geom_n * 1e-4f;
+        o.sh_d = ls.dir;
+        o.sh_tmax = ls.dist - 2e-4f;
+        o.nee_valid = bsdf_pdf > 0.0f;
+        if (o.nee_valid) {
+          o.nee = p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                rt_max(rt_dot(p.normal, ls.dir), 0.0f) / ls.pdf;
+        }
+      }
+    }
+    Scatter sc;
+    if (mat_type == 0u) {
+      sc = sample_diffuse(p.normal, p.albedo, p.rng);
+    } else if (mat_type == 1u) {
+      sc = sample_ggx(p.normal, -p.rd, roughness, f0, p.rng);
+    } else {
+      sc = sample_dielectric(p.rd, p.normal, d1.z, p.albedo, p.rng);
+    }
+    if (mat_type != 2u && rt_dot(sc.dir, p.geom_n) <= 0.0f) {
+      sc.pdf = 0.0f;
+      sc.throughput = rt3_splat(0.0f);
+    }
+    if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) {
+      ended = true;
+    } else {
+      p.throughput = p.throughput * sc.throughput;
+      rt3 offset_n = (rt_dot(sc.dir, p.geom_n) > 0.0f) ? p.geom_n : -p.geom_n;
+      p.ro = hit_p + offset_n * 1e-4f;
+      p.rd = sc.dir;
+      p.prev_pdf = sc.pdf;
+      p.specular = sc.specular;
+      if (p.depth > 3u) {
+        float pr = rt_max(p.throughput.x, rt_max(p.throughput.y, p.throughput.z));
+        if (rand_pcg(p.rng) > pr) {
+          ended = true;
+        } else {
+          p.throughput = p.throughput / pr;
+        }
+      }
+      if (!ended) {
+        if (p.depth < max_depth - 1u) {
+          o.want_extend = true;
+        } else {
+          ended = true;  // depth limit: the loop condition ends the path after this bounce
+        }
+      }
+    }
+  }
+  o.ended = ended;
+}
+
 // number of 16-byte LDS slots the whole scene needs (traversal records + shading arrays)
 __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
                                                   uint32_t n_lights) {
@@ -1318,97 +1425,16 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
 #ifndef RT_WAVE_STATS
       if (DETAIL) cnt_shaded++;
 #endif
-      float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
-      const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
-      const rt3 hit_p = p.ro + p.rd * p.hit_t;
-      p.normal = (rt_dot(p.rd, p.normal) < 0.0f) ? p.normal : -p.normal;
-      p.geom_n = (rt_dot(p.rd, p.geom_n) < 0.0f) ? p.geom_n : -p.geom_n;
-      float metallic = d1.x, roughness = d1.y;
-      if (d2.y > -0.5f) {
-        rt3 mr = sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.y));
-        metallic *= mr.z;
-        roughness *= mr.y;
-      }
-      roughness = rt_max(roughness, 0.005f);
-      rt3 emissive = xyz(d3);
-      if (d2.w > -0.5f) emissive = emissive * sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.w));
-      const rt3 f0 = rt_mix3(rt3_splat(0.04f), p.albedo, metallic);
-
-      bool ended = false;
-      if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
-        rt3 em_val = (mat_type == 3u) ? p.albedo : emissive;
-        if (p.specular) {
-          p.radiance = p.radiance + p.throughput * em_val;
-        } else {
-          p.radiance = p.radiance + p.throughput * em_val *
-                                        power_heuristic(p.prev_pdf, light_pdf(S, U.light_count, p.tri, p.inst, p.hit_t, p.rd));
-        }
-        if (mat_type == 3u) ended = true;
-      }
-      if (!ended) {
-        if (mat_type != 2u) {  // NEE: the 3 draws happen here, the shadow ray is traced below
-          LightSample ls = sample_light(S, U.light_count, hit_p, p.rng);
-          if (ls.pdf > 0.0f) {
-            rt3 bsdf_val = rt3_splat(0.0f);
-            float bsdf_pdf = 0.0f;
-            if (mat_type == 0u) {
-              bsdf_val = p.albedo / RT_PI;
-              bsdf_pdf = rt_max(rt_dot(p.normal, ls.dir), 0.0f) / RT_PI;
-            } else if (mat_type == 1u) {
-              bsdf_val = eval_ggx(p.normal, -p.rd, ls.dir, roughness, f0);
-              rt3 H = rt_normalize(-p.rd + ls.dir);
-              bsdf_pdf = (ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f)) /
-                         (4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
-            }
-            want_shadow = true;  // the reference traces the shadow ray before looking at bsdf_pdf
-            sh_o = hit_p + p.geom_n * 1e-4f;
-            sh_d = ls.dir;
-            sh_tmax = ls.dist - 2e-4f;
-            nee_valid = bsdf_pdf > 0.0f;
-            if (nee_valid) {
-              nee = p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
-                    rt_max(rt_dot(p.normal, ls.dir), 0.0f) / ls.pdf;
-            }
-          }
-        }
-        Scatter sc;
-        if (mat_type == 0u) {
-          sc = sample_diffuse(p.normal, p.albedo, p.rng);
-        } else if (mat_type == 1u) {
-          sc = sample_ggx(p.normal, -p.rd, roughness, f0, p.rng);
-        } else {
-          sc = sample_dielectric(p.rd, p.normal, d1.z, p.albedo, p.rng);
-        }
-        if (mat_type != 2u && rt_dot(sc.dir, p.geom_n) <= 0.0f) {
-          sc.pdf = 0.0f;
-          sc.throughput = rt3_splat(0.0f);
-        }
-        if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) {
-          ended = true;
-        } else {
-          p.throughput = p.throughput * sc.throughput;
-          rt3 offset_n = (rt_dot(sc.dir, p.geom_n) > 0.0f) ? p.geom_n : -p.geom_n;
-          p.ro = hit_p + offset_n * 1e-4f;
-          p.rd = sc.dir;
-          p.prev_pdf = sc.pdf;
-          p.specular = sc.specular;
-          if (p.depth > 3u) {
-            float pr = rt_max(p.throughput.x, rt_max(p.throughput.y, p.throughput.z));
-            if (rand_pcg(p.rng) > pr) {
-              ended = true;
-            } else {
-              p.throughput = p.throughput / pr;
-            }
-          }
-          if (!ended) {
-            if (p.depth < F.max_depth - 1u) {
-              want_extend = true;
-            } else {
-              ended = true;  // depth limit: the loop condition ends the path after this bounce
-            }
-          }
-        }
-      }
+      BounceOut bo;
+      shade_bounce(S, U.light_count, F.max_depth, p, bo);
+      want_shadow = bo.want_shadow;
+      want_extend = bo.want_extend;
+      nee_valid = bo.nee_valid;
+      sh_o = bo.sh_o;
+      sh_d = bo.sh_d;
+      sh_tmax = bo.sh_tmax;
+      nee = bo.nee;
+      const bool ended = bo.ended;
       if (ended) path_done = true;
     }
 
@@ -1484,6 +1510,375 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   c.nodes = cnt_nodes;
   c.tris = cnt_tris;
   c.shaded = cnt_shaded;
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
+// ================================================================== path tracer, wavefront form
+// For scenes whose traversal records do not fit LDS (hundreds of thousands of triangles, a thousand instances) a ray
+// visits 70+ nodes with a long tail, and the per-trip lockstep of the persistent kernel leaves 60 % of the lanes idle
+// while they wait on L2 / Infinity-Cache latency.  The wavefront form splits a bounce into stages with the path state in
+// HBM (84 B per path, 288 GB to spare):
+//   k_wf_shade   one lane per live path: surface frame + shade_bounce(); appends the shadow ray and the extension ray
+//                to device queues (wave-aggregated atomics), finishes paths that end
+//   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result and pulls the
+//                next ray from the queue (batched, >= RT_WF_REFILL lanes), so the slowest ray no longer holds 63 lanes;
+//                same node step / LDS triangle queue as traverse()
+// Stages of one depth run as separate launches in stream order; the host enqueues all depths without reading anything
+// back (queue sizes stay on the device).  Per path the arithmetic, RNG order and f32 addition order are unchanged, so
+// the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
+// Restriction: SPP == 1 (the reference's default); other SPP values use the persistent kernel.
+#define RT_WF_REFILL 16
+
+__device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
+                                              rt3 nee) {
+  W.a[id] = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
+  W.b[id] = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
+  W.c[id] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
+  W.d[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
+  W.e[id] = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
+}
+
+template <bool FIRST, bool DETAIL>
+__global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_scene_uniforms U, WfState W, WfQueues Q,
+                                                  const DevFrameSlot* __restrict__ slots, uint32_t n_slots,
+                                                  uint32_t depth) {
+  const uint32_t npx = U.width * U.height;
+  uint32_t* cnt = Q.counters + 8u * depth;
+  const uint32_t count = FIRST ? npx * n_slots : cnt[0];
+  const uint32_t* active_in = Q.active[depth & 1u];
+  uint32_t cnt_shaded = 0;
+  for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < count; idx += gridDim.x * 256u) {
+    const uint32_t id = FIRST ? idx : active_in[idx];
+    PathState p;
+    p.col = rt3_splat(0.0f);
+    p.sample = 0u;
+    p.pixel = id % npx;
+    if (FIRST) {
+      const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
+      if (!owns_row(F, y)) continue;
+      const DevFrameSlot slot = slots[id / npx];
+      p.rng = init_rng(p.pixel, slot.frame_count);  // SPP == 1: frame_count * SPP + 0
+      rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+      rt3 off = rt3_splat(0.0f);
+      const float lens = U.camera.origin[3];
+      if (lens > 0.0f) {
+        float r = rt_sqrt(rand_pcg(p.rng));
+        float theta = RT_TWO_PI * rand_pcg(p.rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+      rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+      rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+      float u = ((float)x + 0.5f + slot.jitter_x * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + slot.jitter_y * (float)U.height) / (float)U.height;
+      p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      p.ro = cam_o + off;
+      p.throughput = rt3_splat(1.0f);
+      p.radiance = rt3_splat(0.0f);
+      p.prev_pdf = 0.0f;
+      p.specular = true;
+      p.depth = 0u;
+      if (slot.depth[p.pixel] >= 1.0f || F.max_depth == 0u) {  // background (or MAX_DEPTH = 0): black sample
+        F.frame_col[id] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        continue;
+      }
+      float4 g = slot.normal_id[p.pixel];
+      p.tri = rt_f2u(g.z);
+      p.inst = rt_f2u(g.w);
+      setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+    } else {
+      const float4 a = W.a[id], b = W.b[id], c = W.c[id], d = W.d[id], e = W.e[id];
+      p.ro = xyz(a);
+      p.hit_t = a.w;
+      p.rd = xyz(b);
+      p.prev_pdf = b.w;
+      p.throughput = xyz(c);
+      p.rng = rt_f2u(c.w);
+      p.radiance = xyz(d);
+      const uint32_t fl = rt_f2u(d.w);
+      p.depth = fl & 0xffu;
+      p.specular = (fl & WF_FLAG_SPECULAR) != 0u;
+      p.tri = rt_f2u(e.w);
+      p.inst = W.inst[id];
+      setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+    }
+    if (DETAIL) cnt_shaded++;
+    BounceOut bo;
+    shade_bounce(S, U.light_count, F.max_depth, p, bo);
+    if (bo.want_shadow) {
+      const uint32_t pos = atomicAdd(&cnt[1], 1u);
+      Q.shadow_ids[pos] = id;
+      Q.shadow_rays[2 * pos] = make_float4(bo.sh_o.x, bo.sh_o.y, bo.sh_o.z, bo.sh_tmax);
+      Q.shadow_rays[2 * pos + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
+    }
+    if (bo.want_extend) {
+      const uint32_t pos = atomicAdd(&cnt[2], 1u);
+      Q.ext_ids[pos] = id;
+    }
+    if (bo.ended && !bo.want_shadow) {
+      F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
+    } else {
+      const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
+                             (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
+      wf_store_path(W, id, p, flags, bo.nee);
+    }
+  }
+  if (DETAIL) {
+    LaneCounters c = {0, 0, 0, 0, 0, cnt_shaded};
+    flush_counters<true>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+  }
+}
+
+// Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
+// else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
+template <bool ANY, bool DETAIL, bool LDS>
+__global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
+                                                            WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
+                                                            uint32_t n_tris_total, uint32_t n_inst_total) {
+  extern __shared__ f4 s_scene[];
+  WaveWork W;
+  {
+    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+    W.rays = reinterpret_cast<f4*>(wbase);
+    W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  }
+  TravMem M;
+  if (LDS) {
+    f4* dst = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
+    auto stage = [&](const void* src, size_t slots) {
+      const f4* g = reinterpret_cast<const f4*>(src);
+      f4* base = dst;
+      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
+      dst += slots;
+      return base;
+    };
+    M.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    M.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    M.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    __syncthreads();
+  } else {
+    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
+    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
+    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t blas_base = U.blas_base_idx;
+  uint32_t* cnt = Q.counters + 8u * depth;
+  const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
+  uint32_t* head = ANY ? &cnt[3] : &cnt[4];
+  uint32_t* next_active = Q.active[(depth + 1u) & 1u];
+  uint32_t* next_count = Q.counters + 8u * (depth + 1u);
+  const uint32_t tlas_end = blas_base ? rt_f2u(M.nodes[0].w) : 0u;
+
+  // per-lane ray + traversal state
+  bool have_ray = false, searching = false, waiting = false, in_blas = false, any = false;
+  uint32_t id = 0u, leaf = 0u, curr = 0u, end = 0u, base = 0u, tlas_next = 0u, cur_inst = 0u;
+  rt3 o = rt3_splat(0.0f), d = rt3_splat(0.0f);
+  float t_max = 0.0f, closest = 0.0f;
+  int32_t best_tri = -1, best_inst = -1;
+  LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
+  bool queue_left = true;
+  uint32_t n_nodes = 0, n_tris = 0;
+
+  for (;;) {
+    // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
+    const bool done = have_ray && !searching && !waiting;
+    const bool idle = !have_ray || done;
+    const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
+    const unsigned long long busy_m = __ballot(searching || waiting);
+    if (idle_m != 0ull &&
+        ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
+         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+      if (done) {
+        if (ANY) {
+          float4 dd = Ws.d[id];
+          const uint32_t fl = rt_f2u(dd.w);
+          if (!any && (fl & WF_FLAG_NEE_VALID) != 0u) {
+            const float4 e = Ws.e[id];
+            dd.x = dd.x + e.x;  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
+            dd.y = dd.y + e.y;
+            dd.z = dd.z + e.z;
+          }
+          if ((fl & WF_FLAG_ENDED) != 0u)
+            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
+          else
+            Ws.d[id] = dd;
+        } else {
+          if (best_inst < 0) {  // miss: the path ends with what it has
+            const float4 dd = Ws.d[id];
+            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
+          } else {
+            float4 a = Ws.a[id];
+            a.w = closest;
+            Ws.a[id] = a;
+            float4 e = Ws.e[id];
+            e.w = rt_u2f((uint32_t)best_tri);
+            Ws.e[id] = e;
+            Ws.inst[id] = (uint32_t)best_inst;
+            float4 dd = Ws.d[id];
+            const uint32_t fl = rt_f2u(dd.w);
+            dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
+            Ws.d[id] = dd;
+            const uint32_t pos = atomicAdd(&next_count[0], 1u);
+            next_active[pos] = id;
+          }
+        }
+        have_ray = false;
+      }
+      // pull
+      bool need = !have_ray;
+      const unsigned long long need_m = __ballot(need);
+      if (queue_left && need_m != 0ull) {
+        const int leader = __builtin_ctzll(need_m);
+        const uint32_t n_need = (uint32_t)__builtin_popcountll(need_m);
+        uint32_t base_idx = 0;
+        if (lane == (uint32_t)leader) base_idx = atomicAdd(head, n_need);
+        base_idx = __shfl(base_idx, leader, 64);
+        if (base_idx + n_need >= n_rays) queue_left = false;
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+        const uint32_t qi = base_idx + rank;
+        if (need && qi < n_rays) {
+          if (ANY) {
+            id = Q.shadow_ids[qi];
+            const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
+            o = xyz(r0);
+            d = xyz(r1);
+            t_max = r0.w;
+          } else {
+            id = Q.ext_ids[qi];
+            o = xyz(Ws.a[id]);
+            d = xyz(Ws.b[id]);
+            t_max = RT_T_MAX;
+          }
+          have_ray = true;
+          closest = t_max;
+          best_tri = -1;
+          best_inst = -1;
+          any = false;
+          r = make_ray(o, d);
+          curr = 0u;
+          end = tlas_end;
+          base = 0u;
+          in_blas = false;
+          searching = blas_base != 0u;
+          waiting = false;
+        }
+      }
+    }
+    if (__ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+
+    // ---- range exhausted: leave the instance, or finish the ray
+    if (searching && curr >= end) {
+      if (in_blas && tlas_next < tlas_end) {
+        in_blas = false;
+        r = make_ray(o, d);
+        curr = tlas_next;
+        end = tlas_end;
+        base = 0u;
+      } else {
+        searching = false;
+      }
+    }
+    // ---- one node step
+    if (searching) {
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+      if (DETAIL) n_nodes++;
+      const bool hit = hit_box4(lo, hi, r, RT_T_MIN, closest);
+      const uint32_t data = rt_f2u(hi.w);
+      const bool leafhit = hit && data != 0u;
+      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
+      const bool got_leaf = leafhit && in_blas;
+      if (leafhit && !in_blas) {
+        cur_inst = data >> 3;
+        uint32_t off;
+        r = to_instance(M, cur_inst, o, d, off);
+        tlas_next = next;
+        base = blas_base + off;
+        end = base + rt_f2u(M.nodes[2 * base].w);
+        next = base;
+        in_blas = true;
+      }
+      leaf = got_leaf ? data : leaf;
+      waiting = got_leaf;
+      searching = !got_leaf;
+      curr = next;
+    }
+    // ---- flush the triangle queue?
+    const unsigned long long smask = __ballot(searching);
+    const unsigned long long wmask = __ballot(waiting);
+    const uint32_t cntl = waiting ? (leaf & 7u) : 0u;
+    const unsigned long long b0 = __ballot((cntl & 1u) != 0u), b1 = __ballot((cntl & 2u) != 0u), b2 = __ballot((cntl & 4u) != 0u);
+    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                           4u * (uint32_t)__builtin_popcountll(b2);
+    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
+      const uint32_t excl =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+      const uint32_t first = leaf >> 3;
+      if (waiting) {
+        f4 ra, rb;
+        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = RT_T_MIN;
+        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
+        W.rays[2 * lane] = ra;
+        W.rays[2 * lane + 1] = rb;
+        const uint32_t tag = lane << 26;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++)
+          if (i < cntl) W.items[excl + i] = tag | (first + i);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = 0; c < total; c += 64u) {
+        const uint32_t j = c + lane;
+        if (j < total) {
+          const uint32_t it = W.items[j];
+          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
+          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
+          LocalRay q;
+          q.o = rt3_make(ra.x, ra.y, ra.z);
+          q.d = rt3_make(rb.x, rb.y, rb.z);
+          float t;
+          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
+          W.items[j] = rt_f2u(ok ? t : -1.0f);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (waiting) {
+        bool stop = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++) {
+          if (i < cntl && !stop) {
+            if (DETAIL) n_tris++;
+            const float t = rt_u2f(W.items[excl + i]);
+            if (t > 0.0f && t < closest) {
+              if (ANY) {
+                any = true;
+                stop = true;
+              } else {
+                closest = t;
+                best_tri = (int32_t)(first + i);
+                best_inst = (int32_t)cur_inst;
+              }
+            }
+          }
+        }
+        waiting = false;
+        searching = !stop;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // ray counters: the queue length is the number of rays traced
+  LaneCounters c = {0, 0, 0, n_nodes, n_tris, 0};
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (ANY) c.shadow = n_rays; else c.extension = n_rays;
+  }
   flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 

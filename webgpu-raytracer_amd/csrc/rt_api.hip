@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,14 +66,19 @@ struct rt_ctx {
   bool pipeline_built = false;
   bool detailed_counters = false;
   uint32_t stripe_rows = 0, stripe_rank = 0, stripe_count = 1;
-  int variant = 1;        // 1 = persistent waves + path regeneration (default), 0 = one-pixel-per-lane megakernel
+  int variant = 3;        // 3 = auto (default): persistent kernel for LDS-resident scenes, wavefront for larger ones;
+                          // 0 = one-pixel-per-lane megakernel, 1 = persistent kernel, 2 = wavefront
   int num_cus = 256;      // multiProcessorCount of the device
   int occ_blocks[4] = {0, 0, 0, 0};   // cached occupancy query per persistent-kernel variant
+  int wf_occ_blocks[2] = {0, 0};      // ... and for the two wavefront trace kernels
+  size_t wf_occ_dyn = (size_t)-1;
+  int wf_occ_detail = -1;
   size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
   DeviceBuffer frame_col;   // per-frame colours of a batch, added in frame order by k_accumulate_frames
+  DeviceBuffer wf_state, wf_queues, wf_counters;  // wavefront form: path state, ray / path queues, queue counters
 
   // kernel timing
   bool timing = false;
@@ -312,7 +318,7 @@ void rt_destroy(rt_ctx* c) {
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
-                         &c->slots, &c->gbuf_batch, &c->frame_col};
+                         &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -486,6 +492,92 @@ int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32
 
 int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
 
+// Wavefront form: per depth one shade launch and two trace launches, all enqueued without host readback.
+static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, const DevFrameSlot* dslots, uint32_t n,
+                            bool fits_lds) {
+  const size_t npx = (size_t)c->width * c->height;
+  const size_t items = npx * n;
+  if (items >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "batch too large for the wavefront queues");
+  int r = ensure_buffer(c, c->wf_state, items * 84, false);
+  if (r < 0) return r;
+  r = ensure_buffer(c, c->wf_queues, items * 48, false);  // active[2] + shadow ids + ext ids (4 x 4 B) + shadow rays (32 B)
+  if (r < 0) return r;
+  const uint32_t depths = c->max_depth ? c->max_depth : 1u;
+  r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 1) * 32, false);
+  if (r < 0) return r;
+  HIP_TRY(c, hipMemsetAsync(c->wf_counters.ptr, 0, (size_t)(depths + 1) * 32, c->stream));
+  WfState W;
+  char* sb = (char*)c->wf_state.ptr;
+  W.a = (float4*)sb;
+  W.b = (float4*)(sb + items * 16);
+  W.c = (float4*)(sb + items * 32);
+  W.d = (float4*)(sb + items * 48);
+  W.e = (float4*)(sb + items * 64);
+  W.inst = (uint32_t*)(sb + items * 80);
+  WfQueues Q;
+  char* qb = (char*)c->wf_queues.ptr;
+  Q.shadow_rays = (float4*)qb;
+  Q.active[0] = (uint32_t*)(qb + items * 32);
+  Q.active[1] = (uint32_t*)(qb + items * 36);
+  Q.shadow_ids = (uint32_t*)(qb + items * 40);
+  Q.ext_ids = (uint32_t*)(qb + items * 44);
+  Q.counters = (uint32_t*)c->wf_counters.ptr;
+
+  const bool detail = c->detailed_counters;
+  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances) * 16;
+  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  const size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + (trace_lds ? lds_records : 0);
+  const void* trace_fn[2];
+  if (detail) {
+    trace_fn[0] = trace_lds ? (const void*)rtk::k_wf_trace<true, true, true> : (const void*)rtk::k_wf_trace<true, true, false>;
+    trace_fn[1] = trace_lds ? (const void*)rtk::k_wf_trace<false, true, true> : (const void*)rtk::k_wf_trace<false, true, false>;
+  } else {
+    trace_fn[0] = trace_lds ? (const void*)rtk::k_wf_trace<true, false, true> : (const void*)rtk::k_wf_trace<true, false, false>;
+    trace_fn[1] = trace_lds ? (const void*)rtk::k_wf_trace<false, false, true> : (const void*)rtk::k_wf_trace<false, false, false>;
+  }
+  if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_blocks[0] == 0) {
+    for (int k = 0; k < 2; k++) {
+      int per_cu = 0;
+      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], 256, dyn));
+      c->wf_occ_blocks[k] = per_cu < 1 ? 1 : per_cu;
+    }
+    c->wf_occ_dyn = dyn;
+    c->wf_occ_detail = (int)detail;
+  }
+  uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
+  const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * 16);
+  EventPair* ev = next_events(c, 1);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+  for (uint32_t depth = 0; depth < depths; depth++) {
+    if (depth == 0) {
+      if (detail)
+        hipLaunchKernelGGL((rtk::k_wf_shade<true, true>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+      else
+        hipLaunchKernelGGL((rtk::k_wf_shade<true, false>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+    } else {
+      if (detail)
+        hipLaunchKernelGGL((rtk::k_wf_shade<false, true>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+      else
+        hipLaunchKernelGGL((rtk::k_wf_shade<false, false>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+    }
+    for (int k = 0; k < 2; k++) {
+      uint32_t blocks = (uint32_t)c->wf_occ_blocks[k] * (uint32_t)c->num_cus;
+      const uint32_t max_useful = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)0x7fffffff);
+      if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+      DevScene Sa = S;
+      DevFrame Fa = F;
+      rt_scene_uniforms Ua = c->uniforms;
+      void* args[] = {&Sa, &Fa, &Ua, &W, &Q, &depth, &nn, &nt, &ni};
+      HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(256), args, dyn, c->stream));
+    }
+  }
+  if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+  hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots, n,
+                     c->width, c->height);
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
 // compute() for n consecutive frame counts in ONE dispatch of each kernel (n == 1: the plain compute()).
 static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   if (!c || !frame_counts || n == 0) return RT_ERR_INVALID;
@@ -507,14 +599,19 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   if (c->uniforms.light_count > c->n_lights)
     return fail(c, RT_ERR_INVALID, "light_count exceeds the uploaded lights buffer");
   if (c->blas_offset > c->n_nodes) return fail(c, RT_ERR_INVALID, "blas_base_idx exceeds the node buffer");
-  if (c->variant == 0 && n > 1) return fail(c, RT_ERR_INVALID, "batched dispatch needs the persistent kernel form");
+  if (c->variant == 0 && n > 1) return fail(c, RT_ERR_INVALID, "batched dispatch needs the persistent or wavefront kernel form");
   int r = prepare_scene(c);
   if (r < 0) return r;
 
   const size_t npx = (size_t)c->width * c->height;
+  const size_t scene_lds = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
+  const bool fits_lds = scene_lds + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  const bool wavefront = c->spp == 1 && (c->variant == 2 || (c->variant == 3 && !fits_lds));
   if (n > 1) {
     r = ensure_buffer(c, c->gbuf_batch, (size_t)(n - 1) * npx * 24, false);
     if (r < 0) return r;
+  }
+  if (n > 1 || wavefront) {
     r = ensure_buffer(c, c->frame_col, (size_t)n * npx * 16, false);
     if (r < 0) return r;
   }
@@ -540,7 +637,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   DevScene S = dev_scene(c);
   DevFrame F;
   F.accum = accum_ptr(c);
-  F.frame_col = n > 1 ? (float4*)c->frame_col.ptr : nullptr;
+  F.frame_col = (n > 1 || wavefront) ? (float4*)c->frame_col.ptr : nullptr;
   F.albedo = (uint32_t*)c->render_target.ptr;
   F.normal_id = (float4*)c->g_normal.ptr;
   F.depth = (float*)c->g_depth.ptr;
@@ -576,7 +673,10 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
 
   // 2. path trace
-  if (c->variant == 0) {
+  if (wavefront) {
+    r = launch_wavefront(c, S, F, dslots, n, fits_lds);
+    if (r < 0) return r;
+  } else if (c->variant == 0) {
     ev = next_events(c, 1);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     if (c->detailed_counters)
@@ -778,7 +878,7 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
   return RT_OK;
 }
 int rt_set_kernel_variant(rt_ctx* c, int variant) {
-  if (!c || variant < 0 || variant > 1) return RT_ERR_INVALID;
+  if (!c || variant < 0 || variant > 3) return RT_ERR_INVALID;
   c->variant = variant;
   return RT_OK;
 }
