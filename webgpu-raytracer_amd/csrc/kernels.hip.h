@@ -1529,6 +1529,38 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
 // Restriction: SPP == 1 (the reference's default); other SPP values use the persistent kernel.
 #define RT_WF_REFILL 16
 
+// Device queues are filled and drained in chunks of RT_WF_CHUNK entries: a wave reserves a chunk with ONE atomic
+// and then appends with ballot/mbcnt ranks (a queue counter is a single address: ~88 atomics/us chip-wide, so one atomic
+// per wave-append or per 16-ray pull caps a stage at a few Grays/s). Unused tail entries of a chunk hold RT_WF_INVALID.
+#define RT_WF_CHUNK 256u
+#define RT_WF_INVALID 0xffffffffu
+struct WaveQueueWriter {
+  uint32_t pos, end;  // wave-uniform cursor into the current chunk
+};
+// returns the slot for lanes with want == true (RT_WF_INVALID otherwise); call from wave-uniform control flow
+__device__ __forceinline__ uint32_t wq_append(WaveQueueWriter& w, uint32_t* counter, uint32_t* ids, bool want) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return RT_WF_INVALID;
+  const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+  if (w.pos + n > w.end) {
+    for (uint32_t i = w.pos + lane; i < w.end; i += 64u) ids[i] = RT_WF_INVALID;
+    uint32_t b = 0;
+    if (lane == 0u) b = atomicAdd(counter, RT_WF_CHUNK);
+    b = __shfl(b, 0, 64);
+    w.pos = b;
+    w.end = b + RT_WF_CHUNK;
+  }
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  const uint32_t slot = w.pos + rank;
+  w.pos += n;
+  return want ? slot : RT_WF_INVALID;
+}
+__device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* ids) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i = w.pos + lane; i < w.end; i += 64u) ids[i] = RT_WF_INVALID;
+}
+
 __device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
                                               rt3 nee) {
   W.a[id] = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
@@ -1547,15 +1579,33 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
   const uint32_t count = FIRST ? npx * n_slots : cnt[0];
   const uint32_t* active_in = Q.active[depth & 1u];
   uint32_t cnt_shaded = 0;
-  for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < count; idx += gridDim.x * 256u) {
-    const uint32_t id = FIRST ? idx : active_in[idx];
+  WaveQueueWriter wq_shadow = {0u, 0u}, wq_ext = {0u, 0u};
+  // wave-uniform loop (every lane of a wave takes part in the queue appends)
+  for (uint32_t base_idx = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base_idx < count; base_idx += gridDim.x * 256u) {
+    const uint32_t idx = base_idx + (threadIdx.x & 63u);
+    bool live = idx < count;
+    uint32_t id = 0u;
+    if (live) {
+      id = FIRST ? idx : active_in[idx];
+      live = id != RT_WF_INVALID;
+    }
+    BounceOut bo;
+    bo.want_shadow = bo.want_extend = bo.nee_valid = bo.ended = false;
+    bo.sh_o = bo.sh_d = bo.nee = rt3_splat(0.0f);
+    bo.sh_tmax = 0.0f;
     PathState p;
     p.col = rt3_splat(0.0f);
     p.sample = 0u;
     p.pixel = id % npx;
+    p.tri = p.inst = p.depth = p.rng = 0u;
+    p.hit_t = p.prev_pdf = 0.0f;
+    p.specular = true;
+    p.ro = p.rd = p.throughput = p.radiance = p.normal = p.geom_n = p.albedo = rt3_splat(0.0f);
+    p.tex_uv = rt2_make(0.0f, 0.0f);
+    if (live) {
     if (FIRST) {
       const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
-      if (!owns_row(F, y)) continue;
+      if (!owns_row(F, y)) live = false;
       const DevFrameSlot slot = slots[id / npx];
       p.rng = init_rng(p.pixel, slot.frame_count);  // SPP == 1: frame_count * SPP + 0
       rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
@@ -1583,14 +1633,16 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
       p.prev_pdf = 0.0f;
       p.specular = true;
       p.depth = 0u;
-      if (slot.depth[p.pixel] >= 1.0f || F.max_depth == 0u) {  // background (or MAX_DEPTH = 0): black sample
+      if (live && (slot.depth[p.pixel] >= 1.0f || F.max_depth == 0u)) {  // background (or MAX_DEPTH = 0): black sample
         F.frame_col[id] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        continue;
+        live = false;
       }
-      float4 g = slot.normal_id[p.pixel];
-      p.tri = rt_f2u(g.z);
-      p.inst = rt_f2u(g.w);
-      setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+      if (live) {
+        float4 g = slot.normal_id[p.pixel];
+        p.tri = rt_f2u(g.z);
+        p.inst = rt_f2u(g.w);
+        setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+      }
     } else {
       const float4 a = W.a[id], b = W.b[id], c = W.c[id], d = W.d[id], e = W.e[id];
       p.ro = xyz(a);
@@ -1607,27 +1659,31 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
       p.inst = W.inst[id];
       setup_surface(S, p, false, 0.0f, 0.0f, 0u);
     }
-    if (DETAIL) cnt_shaded++;
-    BounceOut bo;
-    shade_bounce(S, U.light_count, F.max_depth, p, bo);
-    if (bo.want_shadow) {
-      const uint32_t pos = atomicAdd(&cnt[1], 1u);
-      Q.shadow_ids[pos] = id;
-      Q.shadow_rays[2 * pos] = make_float4(bo.sh_o.x, bo.sh_o.y, bo.sh_o.z, bo.sh_tmax);
-      Q.shadow_rays[2 * pos + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
+    if (live) {
+      if (DETAIL) cnt_shaded++;
+      shade_bounce(S, U.light_count, F.max_depth, p, bo);
     }
-    if (bo.want_extend) {
-      const uint32_t pos = atomicAdd(&cnt[2], 1u);
-      Q.ext_ids[pos] = id;
+    }  // if (live) — everything below runs for the whole wave
+    const uint32_t sslot = wq_append(wq_shadow, &cnt[1], Q.shadow_ids, live && bo.want_shadow);
+    if (sslot != RT_WF_INVALID) {
+      Q.shadow_ids[sslot] = id;
+      Q.shadow_rays[2 * sslot] = make_float4(bo.sh_o.x, bo.sh_o.y, bo.sh_o.z, bo.sh_tmax);
+      Q.shadow_rays[2 * sslot + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
     }
-    if (bo.ended && !bo.want_shadow) {
-      F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
-    } else {
-      const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
-                             (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
-      wf_store_path(W, id, p, flags, bo.nee);
+    const uint32_t eslot = wq_append(wq_ext, &cnt[2], Q.ext_ids, live && bo.want_extend);
+    if (eslot != RT_WF_INVALID) Q.ext_ids[eslot] = id;
+    if (live) {
+      if (bo.ended && !bo.want_shadow) {
+        F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
+      } else {
+        const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
+                               (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
+        wf_store_path(W, id, p, flags, bo.nee);
+      }
     }
   }
+  wq_finish(wq_shadow, Q.shadow_ids);
+  wq_finish(wq_ext, Q.ext_ids);
   if (DETAIL) {
     LaneCounters c = {0, 0, 0, 0, 0, cnt_shaded};
     flush_counters<true>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -1683,7 +1739,9 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
   int32_t best_tri = -1, best_inst = -1;
   LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
   bool queue_left = true;
-  uint32_t n_nodes = 0, n_tris = 0;
+  uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
+  WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
+  uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
 
   for (;;) {
     // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
@@ -1694,6 +1752,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
          (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+      bool push_next = false;
       if (done) {
         if (ANY) {
           float4 dd = Ws.d[id];
@@ -1724,54 +1783,68 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
             const uint32_t fl = rt_f2u(dd.w);
             dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
             Ws.d[id] = dd;
-            const uint32_t pos = atomicAdd(&next_count[0], 1u);
-            next_active[pos] = id;
+            push_next = true;
           }
         }
         have_ray = false;
       }
-      // pull
-      bool need = !have_ray;
+      if (!ANY) {
+        const uint32_t slot = wq_append(wq_next, &next_count[0], next_active, push_next);
+        if (slot != RT_WF_INVALID) next_active[slot] = id;
+      }
+      // pull: needy lanes take consecutive entries of the wave's chunk; a new chunk costs one atomic
+      const bool need = !have_ray;
       const unsigned long long need_m = __ballot(need);
       if (queue_left && need_m != 0ull) {
-        const int leader = __builtin_ctzll(need_m);
-        const uint32_t n_need = (uint32_t)__builtin_popcountll(need_m);
-        uint32_t base_idx = 0;
-        if (lane == (uint32_t)leader) base_idx = atomicAdd(head, n_need);
-        base_idx = __shfl(base_idx, leader, 64);
-        if (base_idx + n_need >= n_rays) queue_left = false;
-        const uint32_t rank =
-            __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
-        const uint32_t qi = base_idx + rank;
-        if (need && qi < n_rays) {
-          if (ANY) {
-            id = Q.shadow_ids[qi];
-            const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
-            o = xyz(r0);
-            d = xyz(r1);
-            t_max = r0.w;
+        if (chunk_pos >= chunk_end) {
+          uint32_t bq = 0;
+          if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+          bq = __shfl(bq, 0, 64);
+          if (bq >= n_rays) {
+            queue_left = false;
           } else {
-            id = Q.ext_ids[qi];
-            o = xyz(Ws.a[id]);
-            d = xyz(Ws.b[id]);
-            t_max = RT_T_MAX;
+            chunk_pos = bq;
+            chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
           }
-          have_ray = true;
-          closest = t_max;
-          best_tri = -1;
-          best_inst = -1;
-          any = false;
-          r = make_ray(o, d);
-          curr = 0u;
-          end = tlas_end;
-          base = 0u;
-          in_blas = false;
-          searching = blas_base != 0u;
-          waiting = false;
+        }
+        if (queue_left) {
+          const uint32_t rank =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+          const uint32_t qi = chunk_pos + rank;
+          chunk_pos += (uint32_t)__builtin_popcountll(need_m);
+          if (need && qi < chunk_end) {
+            const uint32_t rid = ANY ? Q.shadow_ids[qi] : Q.ext_ids[qi];
+            if (rid != RT_WF_INVALID) {
+              id = rid;
+              if (ANY) {
+                const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
+                o = xyz(r0);
+                d = xyz(r1);
+                t_max = r0.w;
+              } else {
+                o = xyz(Ws.a[id]);
+                d = xyz(Ws.b[id]);
+                t_max = RT_T_MAX;
+              }
+              n_traced++;
+              have_ray = true;
+              closest = t_max;
+              best_tri = -1;
+              best_inst = -1;
+              any = false;
+              r = make_ray(o, d);
+              curr = 0u;
+              end = tlas_end;
+              base = 0u;
+              in_blas = false;
+              searching = blas_base != 0u;
+              waiting = false;
+            }
+          }
         }
       }
     }
-    if (__ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+    if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
 
     // ---- range exhausted: leave the instance, or finish the ray
     if (searching && curr >= end) {
@@ -1874,11 +1947,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // ray counters: the queue length is the number of rays traced
-  LaneCounters c = {0, 0, 0, n_nodes, n_tris, 0};
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (ANY) c.shadow = n_rays; else c.extension = n_rays;
-  }
+  if (!ANY) wq_finish(wq_next, next_active);
+  LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
   flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 

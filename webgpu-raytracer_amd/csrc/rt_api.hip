@@ -500,7 +500,9 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   if (items >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "batch too large for the wavefront queues");
   int r = ensure_buffer(c, c->wf_state, items * 84, false);
   if (r < 0) return r;
-  r = ensure_buffer(c, c->wf_queues, items * 48, false);  // active[2] + shadow ids + ext ids (4 x 4 B) + shadow rays (32 B)
+  // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
+  const size_t qcap = items + (size_t)5 * 1024 * 1024;
+  r = ensure_buffer(c, c->wf_queues, qcap * 48, false);  // active[2] + shadow ids + ext ids (4 x 4 B) + shadow rays (32 B)
   if (r < 0) return r;
   const uint32_t depths = c->max_depth ? c->max_depth : 1u;
   r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 1) * 32, false);
@@ -517,10 +519,10 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   WfQueues Q;
   char* qb = (char*)c->wf_queues.ptr;
   Q.shadow_rays = (float4*)qb;
-  Q.active[0] = (uint32_t*)(qb + items * 32);
-  Q.active[1] = (uint32_t*)(qb + items * 36);
-  Q.shadow_ids = (uint32_t*)(qb + items * 40);
-  Q.ext_ids = (uint32_t*)(qb + items * 44);
+  Q.active[0] = (uint32_t*)(qb + qcap * 32);
+  Q.active[1] = (uint32_t*)(qb + qcap * 36);
+  Q.shadow_ids = (uint32_t*)(qb + qcap * 40);
+  Q.ext_ids = (uint32_t*)(qb + qcap * 44);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
 
   const bool detail = c->detailed_counters;
