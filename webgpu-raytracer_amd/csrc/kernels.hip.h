@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 // Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
 // else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
 template <bool ANY, bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
+__global__ __launch_bounds__(256, LDS ? 4 : 8) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
                                                             WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
                                                             uint32_t n_tris_total, uint32_t n_inst_total) {
   extern __shared__ f4 s_scene[];
@@ -1738,6 +1738,11 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
   float t_max = 0.0f, closest = 0.0f;
   int32_t best_tri = -1, best_inst = -1;
   LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
+  // the DFS-next node (curr + 1) is fetched together with the current one: it usually shares its cache line, and
+  // when the slab test descends (internal node hit) the next step finds its node already in registers instead of
+  // starting a dependent L2 / Infinity-Cache round trip
+  f4 pf_lo = {0.0f, 0.0f, 0.0f, 0.0f}, pf_hi = {0.0f, 0.0f, 0.0f, 0.0f};
+  uint32_t pf_idx = RT_WF_INVALID;
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
   WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
@@ -1860,7 +1865,20 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_wf_trace(DevScene Sg, DevF
     }
     // ---- one node step
     if (searching) {
-      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+      f4 lo, hi;
+      if (!LDS && pf_idx == curr) {
+        lo = pf_lo;
+        hi = pf_hi;
+      } else {
+        lo = M.nodes[2 * curr];
+        hi = M.nodes[2 * curr + 1];
+      }
+      if (!LDS) {  // curr + 1 < n_nodes_total is guaranteed inside a subtree except at the very last node
+        const uint32_t nx = curr + 1u < n_nodes_total ? curr + 1u : curr;
+        pf_lo = M.nodes[2 * nx];
+        pf_hi = M.nodes[2 * nx + 1];
+        pf_idx = nx;
+      }
       if (DETAIL) n_nodes++;
       const bool hit = hit_box4(lo, hi, r, RT_T_MIN, closest);
       const uint32_t data = rt_f2u(hi.w);
