@@ -140,8 +140,12 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
  * (HIP events recorded on the context stream around each launch); also returns the launch count. */
 int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
 int rt_set_kernel_timing(rt_ctx* ctx, int enabled);
-/* Path-trace kernel form: 1 = persistent waves with per-lane path regeneration (default),
- * 0 = one pixel per lane, one 8x8 tile per wave (the reference's dispatch shape; kept for A/B timing). */
+/* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
+ *   3 = auto (default): persistent kernel when the scene's records fit LDS, wavefront form otherwise (SPP == 1)
+ *   2 = wavefront: shade / trace stages per depth, path state in HBM, ray-level regeneration in the trace kernels
+ *       (SPP != 1 falls back to the persistent kernel)
+ *   1 = persistent waves with per-lane path regeneration
+ *   0 = one pixel per lane, one 8x8 tile per wave (the reference's dispatch shape; kept for A/B timing; no batches) */
 int rt_set_kernel_variant(rt_ctx* ctx, int variant);
 int rt_device_count(void);
 

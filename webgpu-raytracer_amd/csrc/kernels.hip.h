@@ -948,12 +948,20 @@ struct WaveWork {
   uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
 };
 #define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 6
+#endif
+#ifndef RT_PF
+#define RT_PF 0
+#endif
 #ifndef RT_FLUSH_ITEMS
 #define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
                             // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
 #endif
 
-template <bool ANY, bool COUNT>
+// PF (global-memory scenes): the DFS-next node (curr + 1) is fetched together with the current one — it usually shares
+// its cache line — so a step that descends finds its node in registers instead of starting a dependent round trip.
+template <bool ANY, bool COUNT, bool PF = false>
 __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
                                          rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
                                          int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
@@ -969,6 +977,8 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
   uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
   uint32_t cur_inst = 0u;
   bool in_blas = false;
+  f4 pf_lo = {0.0f, 0.0f, 0.0f, 0.0f}, pf_hi = {0.0f, 0.0f, 0.0f, 0.0f};
+  uint32_t pf_idx = 0xffffffffu;
   for (;;) {
 #ifdef RT_WAVE_STATS
     {
@@ -990,7 +1000,20 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
     }
     // ---- one node step for every searching lane (curr < end holds); select-based, two branches only
     if (searching) {
-      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+      f4 lo, hi;
+      if (PF && pf_idx == curr) {
+        lo = pf_lo;
+        hi = pf_hi;
+      } else {
+        lo = M.nodes[2 * curr];
+        hi = M.nodes[2 * curr + 1];
+      }
+      if (PF) {
+        const uint32_t nx = curr + 1u < end ? curr + 1u : curr;
+        pf_lo = M.nodes[2 * nx];
+        pf_hi = M.nodes[2 * nx + 1];
+        pf_idx = nx;
+      }
 #ifndef RT_WAVE_STATS
       if (COUNT) n_nodes++;
 #endif
@@ -1449,7 +1472,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t a_, b_;
       bool occluded;
-      traverse<true, DETAIL>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
+      traverse<true, DETAIL, RT_PF && !LDS>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
                              cnt_nodes, cnt_tris);
       if (want_shadow) {
         cnt_shadow++;
@@ -1462,7 +1485,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t tri_, inst_;
       bool any_;
-      traverse<false, DETAIL>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
+      traverse<false, DETAIL, RT_PF && !LDS>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
                               cnt_nodes, cnt_tris);
       if (want_extend) {
         cnt_ext++;
@@ -1693,7 +1716,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 // Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
 // else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
 template <bool ANY, bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256, LDS ? 4 : 8) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
+__global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
                                                             WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
                                                             uint32_t n_tris_total, uint32_t n_inst_total) {
   extern __shared__ f4 s_scene[];
@@ -1866,14 +1889,14 @@ __global__ __launch_bounds__(256, LDS ? 4 : 8) void k_wf_trace(DevScene Sg, DevF
     // ---- one node step
     if (searching) {
       f4 lo, hi;
-      if (!LDS && pf_idx == curr) {
+      if (RT_PF && !LDS && pf_idx == curr) {
         lo = pf_lo;
         hi = pf_hi;
       } else {
         lo = M.nodes[2 * curr];
         hi = M.nodes[2 * curr + 1];
       }
-      if (!LDS) {  // curr + 1 < n_nodes_total is guaranteed inside a subtree except at the very last node
+      if (RT_PF && !LDS) {  // curr + 1 < n_nodes_total is guaranteed inside a subtree except at the very last node
         const uint32_t nx = curr + 1u < n_nodes_total ? curr + 1u : curr;
         pf_lo = M.nodes[2 * nx];
         pf_hi = M.nodes[2 * nx + 1];

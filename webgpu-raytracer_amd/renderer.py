@@ -236,7 +236,8 @@ class WebGPURenderer:
         self._check(self.L.rt_set_stream(self.ctx, ctypes.c_void_p(hip_stream_handle)), "setStream")
 
     def setKernelVariant(self, variant):
-        """1 = persistent waves + path regeneration (default), 0 = one pixel per lane megakernel"""
+        """3 = auto (default: persistent kernel for LDS-resident scenes, wavefront form for larger ones), 2 = wavefront,
+        1 = persistent waves + path regeneration, 0 = one pixel per lane megakernel; all bit-identical"""
         self._check(self.L.rt_set_kernel_variant(self.ctx, int(variant)), "setKernelVariant")
 
     def setKernelTiming(self, enabled):
