@@ -951,17 +951,12 @@ struct WaveWork {
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 6
 #endif
-#ifndef RT_PF
-#define RT_PF 0
-#endif
 #ifndef RT_FLUSH_ITEMS
 #define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
                             // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
 #endif
 
-// PF (global-memory scenes): the DFS-next node (curr + 1) is fetched together with the current one — it usually shares
-// its cache line — so a step that descends finds its node in registers instead of starting a dependent round trip.
-template <bool ANY, bool COUNT, bool PF = false>
+template <bool ANY, bool COUNT>
 __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
                                          rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
                                          int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
@@ -977,8 +972,6 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
   uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
   uint32_t cur_inst = 0u;
   bool in_blas = false;
-  f4 pf_lo = {0.0f, 0.0f, 0.0f, 0.0f}, pf_hi = {0.0f, 0.0f, 0.0f, 0.0f};
-  uint32_t pf_idx = 0xffffffffu;
   for (;;) {
 #ifdef RT_WAVE_STATS
     {
@@ -1000,20 +993,7 @@ __device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, ui
     }
     // ---- one node step for every searching lane (curr < end holds); select-based, two branches only
     if (searching) {
-      f4 lo, hi;
-      if (PF && pf_idx == curr) {
-        lo = pf_lo;
-        hi = pf_hi;
-      } else {
-        lo = M.nodes[2 * curr];
-        hi = M.nodes[2 * curr + 1];
-      }
-      if (PF) {
-        const uint32_t nx = curr + 1u < end ? curr + 1u : curr;
-        pf_lo = M.nodes[2 * nx];
-        pf_hi = M.nodes[2 * nx + 1];
-        pf_idx = nx;
-      }
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
 #ifndef RT_WAVE_STATS
       if (COUNT) n_nodes++;
 #endif
@@ -1472,7 +1452,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t a_, b_;
       bool occluded;
-      traverse<true, DETAIL, RT_PF && !LDS>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
+      traverse<true, DETAIL>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
                              cnt_nodes, cnt_tris);
       if (want_shadow) {
         cnt_shadow++;
@@ -1485,7 +1465,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t tri_, inst_;
       bool any_;
-      traverse<false, DETAIL, RT_PF && !LDS>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
+      traverse<false, DETAIL>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
                               cnt_nodes, cnt_tris);
       if (want_extend) {
         cnt_ext++;
@@ -1761,11 +1741,6 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
   float t_max = 0.0f, closest = 0.0f;
   int32_t best_tri = -1, best_inst = -1;
   LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
-  // the DFS-next node (curr + 1) is fetched together with the current one: it usually shares its cache line, and
-  // when the slab test descends (internal node hit) the next step finds its node already in registers instead of
-  // starting a dependent L2 / Infinity-Cache round trip
-  f4 pf_lo = {0.0f, 0.0f, 0.0f, 0.0f}, pf_hi = {0.0f, 0.0f, 0.0f, 0.0f};
-  uint32_t pf_idx = RT_WF_INVALID;
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
   WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
@@ -1888,20 +1863,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
     }
     // ---- one node step
     if (searching) {
-      f4 lo, hi;
-      if (RT_PF && !LDS && pf_idx == curr) {
-        lo = pf_lo;
-        hi = pf_hi;
-      } else {
-        lo = M.nodes[2 * curr];
-        hi = M.nodes[2 * curr + 1];
-      }
-      if (RT_PF && !LDS) {  // curr + 1 < n_nodes_total is guaranteed inside a subtree except at the very last node
-        const uint32_t nx = curr + 1u < n_nodes_total ? curr + 1u : curr;
-        pf_lo = M.nodes[2 * nx];
-        pf_hi = M.nodes[2 * nx + 1];
-        pf_idx = nx;
-      }
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
       if (DETAIL) n_nodes++;
       const bool hit = hit_box4(lo, hi, r, RT_T_MIN, closest);
       const uint32_t data = rt_f2u(hi.w);
