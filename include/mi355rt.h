@@ -75,6 +75,17 @@ int rt_reset_accum(rt_ctx* ctx);
  * Takes the already decoded + resized 1024x1024 RGBA8 layers (decode/resize is the
  * browser's job in the reference).  layers == 0 binds the 1x1 white default texture. */
 int rt_upload_textures(rt_ctx* ctx, const uint8_t* rgba, uint32_t layers);
+/* The same method fed with images at their own size: the host decodes each blob
+ * (include/mi355tex.h), the GPU resizes it into its layer — createImageBitmap(blob, {resizeWidth: 1024,
+ * resizeHeight: 1024}) + copyExternalImageToTexture, ResourceManager.ts:162-196; resize rule: mi355rt_math.h
+ * rt_resize_coord / rt_bilinear_u8.
+ *   rt_alloc_texture_layers   createTexture({size: [1024, 1024, layers]}); every layer starts as the white fallback
+ *   rt_upload_texture_image   layer <- width x height straight-alpha RGBA8; rgba == NULL writes the white fallback
+ *                             bitmap the reference substitutes when decoding fails (:169-175, 200-208)
+ *   rt_read_texture_layer     1024*1024*4 bytes back to the host (tests) */
+int rt_alloc_texture_layers(rt_ctx* ctx, uint32_t layers);
+int rt_upload_texture_image(rt_ctx* ctx, uint32_t layer, const uint8_t* rgba, uint32_t width, uint32_t height);
+int rt_read_texture_layer(rt_ctx* ctx, uint32_t layer, uint8_t* out_rgba, size_t cap);
 
 /* updateBuffer(type, data) -> needsRebind — WebGPURenderer.ts:55-60, ResourceManager.ts:230-284 */
 int rt_upload(rt_ctx* ctx, rt_kind kind, const void* data, size_t bytes);

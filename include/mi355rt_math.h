@@ -302,4 +302,25 @@ RT_HD float rt_f16_to_f32(uint16_t h) {
   return rt_u2f(sign | ((e + 112u) << 23) | (m << 13));
 }
 
+/* ------------------------------------------------ texture ingest: resize to the 1024 x 1024 layer
+ * createImageBitmap(blob, {resizeWidth: 1024, resizeHeight: 1024}) with the default resizeQuality "low"
+ * (ResourceManager.ts:164-168): bilinear, pixel centres aligned, clamp to edge, per channel on straight RGBA8.
+ * rt_resize_coord: source coordinate of destination texel d (0..dst-1) for a source of `src` texels: returns the
+ * left/top texel index in *i0, its neighbour in *i1 and the weight of the neighbour. src == dst gives weight 0. */
+RT_HD float rt_resize_coord(uint32_t d, uint32_t src, uint32_t dst, uint32_t* i0, uint32_t* i1) {
+  float s = ((float)d + 0.5f) * ((float)src / (float)dst) - 0.5f;
+  s = rt_clamp(s, 0.0f, (float)(src - 1u));
+  float fl = rt_floor(s);
+  uint32_t a = (uint32_t)fl;
+  *i0 = a;
+  *i1 = a + 1u < src ? a + 1u : src - 1u;
+  return s - fl;
+}
+RT_HD uint32_t rt_bilinear_u8(uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11, float fx, float fy) {
+  float top = (float)c00 + ((float)c10 - (float)c00) * fx;
+  float bot = (float)c01 + ((float)c11 - (float)c01) * fx;
+  float v = top + (bot - top) * fy;
+  return (uint32_t)rt_floor(rt_clamp(v, 0.0f, 255.0f) + 0.5f);
+}
+
 #endif /* MI355RT_MATH_H */

@@ -1003,6 +1003,29 @@ void oracle_upload_textures(oracle_ctx* c, const uint8_t* rgba, uint32_t layers)
   c->o.tex_layers = layers;
   c->o.tex.assign(rgba, rgba + (size_t)layers * RT_TEX_SIZE * RT_TEX_SIZE * 4);
 }
+// One 1024 x 1024 layer from a w x h RGBA8 image: createImageBitmap(blob, {resizeWidth: 1024, resizeHeight: 1024})
+// with the default resizeQuality "low" (ResourceManager.ts:164-168) restated as bilinear, pixel centres aligned,
+// clamp to edge (include/mi355rt_math.h rt_resize_coord / rt_bilinear_u8).  rgba == nullptr: the white fallback
+// bitmap (:200-208).  The browser's own filter is not pinned by the reference (parity unpinned, see header).
+void oracle_resize_texture(const uint8_t* rgba, uint32_t w, uint32_t h, uint8_t* out) {
+  for (uint32_t y = 0; y < RT_TEX_SIZE; y++) {
+    for (uint32_t x = 0; x < RT_TEX_SIZE; x++) {
+      uint8_t* o = out + ((size_t)y * RT_TEX_SIZE + x) * 4;
+      if (!rgba) {
+        o[0] = o[1] = o[2] = o[3] = 255;
+        continue;
+      }
+      uint32_t x0, x1, y0, y1;
+      const float fx = rt_resize_coord(x, w, RT_TEX_SIZE, &x0, &x1);
+      const float fy = rt_resize_coord(y, h, RT_TEX_SIZE, &y0, &y1);
+      for (int k = 0; k < 4; k++) {
+        const uint32_t c00 = rgba[((size_t)y0 * w + x0) * 4 + k], c10 = rgba[((size_t)y0 * w + x1) * 4 + k];
+        const uint32_t c01 = rgba[((size_t)y1 * w + x0) * 4 + k], c11 = rgba[((size_t)y1 * w + x1) * 4 + k];
+        o[k] = (uint8_t)rt_bilinear_u8(c00, c10, c01, c11, fx, fy);
+      }
+    }
+  }
+}
 void oracle_update_topology(oracle_ctx* c, const uint32_t* data, size_t n_u32) {
   c->o.topology.resize(n_u32 / 20);
   std::memcpy(c->o.topology.data(), data, (n_u32 / 20) * sizeof(rt_topology));

@@ -43,7 +43,7 @@ def lib():
             "oracle_compute": [vp, u32], "oracle_present": [vp], "oracle_capture_frame": [vp, vp],
             "oracle_read_accum": [vp, vp], "oracle_write_accum": [vp, vp], "oracle_read_gbuffer": [vp, vp, vp, vp],
             "oracle_read_history": [vp, vp], "oracle_read_uniforms": [vp, vp], "oracle_get_counters": [vp, vp],
-            "oracle_reset_counters": [vp],
+            "oracle_reset_counters": [vp], "oracle_resize_texture": [vp, u32, u32, vp],
         }.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None

@@ -38,10 +38,20 @@ def test_scene_library_exports_every_declared_symbol(W):
         assert hasattr(lib, n), "libmi355scene.so does not export %s" % n
 
 
+def test_texture_library_exports_every_declared_symbol(W):
+    lib = ctypes.CDLL(W._build.build_tex())
+    names = declared_symbols("mi355tex.h", "mt_")
+    assert len(names) >= 5
+    for n in names:
+        assert hasattr(lib, n), "libmi355tex.so does not export %s" % n
+    assert sorted(W.textures.TEX_EXPORTED_SYMBOLS) == names
+    W.textures.load_tex_library()
+
+
 def test_library_is_gfx950_code_object(W, rt_lib):
     blob = open(W._build.RT_LIB, "rb").read()
     assert b"gfx950" in blob
-    for kernel in (b"k_pathtrace", b"k_primary_visibility", b"k_postprocess", b"k_prepare_tris"):
+    for kernel in (b"k_pathtrace", b"k_primary_visibility", b"k_postprocess", b"k_prepare_tris", b"k_resize_texture"):
         assert kernel in blob
 
 

@@ -66,3 +66,41 @@ def test_javascript_driven_render_matches_the_oracle(W, oracle_lib, addon):
     assert got["counters"]["primary_rays"] == c["primary_rays"]
     assert got["counters"]["extension_rays"] == c["extension_rays"]
     assert got["counters"]["shadow_rays"] == c["shadow_rays"]
+
+
+@needs_node
+def test_javascript_bridge_hands_out_png_that_decodes_to_the_layer(W, addon):
+    """world-bridge.ts getTexture(): encoded bytes. The JS bridge's PNG goes through mtDecode (the addon's binding of
+    mt_decode) and must give back the scene's raw layer."""
+    js = ("const {WorldBridge}=require('%s/index.js');const n=require('%s/mi355rt.node');const c=require('crypto');"
+          "(async()=>{const b=new WorldBridge();await b.loadScene('sponza_like');const png=b.getTexture(2);"
+          "const img=n.mtDecode(png);let bad=null;try{n.mtDecode(new Uint8Array([1,2,3]))}catch(e){bad=e.message}"
+          "console.log(JSON.stringify({count:b.textureCount,w:img.width,h:img.height,bad,"
+          "sha:c.createHash('sha256').update(Buffer.from(img.data.buffer)).digest('hex'),"
+          "magic:Buffer.from(png.buffer,png.byteOffset,4).toString('latin1')}));})()" % (NODE_DIR, NODE_DIR))
+    out = subprocess.run([node, "-e", js], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    b = W.WorldBridge()
+    b.loadScene("sponza_like")
+    assert got["count"] == 8 and got["w"] == 1024 and got["h"] == 1024 and got["magic"] == "\x89PNG"
+    assert got["bad"] == "not a PNG or JPEG image"
+    assert hashlib.sha256(b.getTextureRGBA(2).tobytes()).hexdigest() == got["sha"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_javascript_textured_render_matches_the_oracle(W, oracle_lib, addon):
+    """sponza_like from JS: loadTexturesFromWorld = PNG -> mtDecode -> rtUploadTextureImage (GPU resize)."""
+    out = subprocess.run([node, os.path.join(NODE_DIR, "render_cornell.js"), "sponza_like", "64", "40", "2", "5"],
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    b = W.WorldBridge()
+    b.loadScene("sponza_like")
+    cpu = oracle_lib.OracleRenderer()
+    cpu.buildPipeline(5, 1)
+    W.upload_scene(cpu, b, 64, 40)
+    for f in (1, 2):
+        cpu.compute(f)
+        cpu.present()
+    assert hashlib.sha256(cpu.readAccum().tobytes()).hexdigest() == got["accum_sha256"]
+    assert hashlib.sha256(cpu.captureFrame()["data"].tobytes()).hexdigest() == got["rgba_sha256"]

@@ -10,8 +10,9 @@ from . import _build
 from .world_bridge import WorldBridge
 from .renderer import WebGPURenderer, RendererError, upload_scene
 from .recorder import FrameLoop
+from . import textures
 
-__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "FrameLoop", "build"]
+__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "FrameLoop", "textures", "build"]
 
 
 def build(force=False):

@@ -2,6 +2,7 @@
 
   lib/libmi355scene.so   g++    csrc/scene/scene_compiler.cpp      (host, scene compiler)
   lib/libmi355rt.so      hipcc  csrc/rt_api.hip (+ kernels)        (gfx950, the C-ABI renderer)
+  lib/libmi355tex.so     g++    csrc/texture/image_decode.cpp      (host, PNG / JPEG decode for texture ingest)
   node/mi355rt.node      gcc    node/addon.c                       (N-API shim over libmi355rt.so)
 
 Outputs are git-ignored (*.so) but travel to the GPU box with the gpurun snapshot.
@@ -18,6 +19,7 @@ INCLUDE = os.path.join(REPO_DIR, "include")
 
 SCENE_LIB = os.path.join(LIB_DIR, "libmi355scene.so")
 RT_LIB = os.path.join(LIB_DIR, "libmi355rt.so")
+TEX_LIB = os.path.join(LIB_DIR, "libmi355tex.so")
 NODE_ADDON = os.path.join(PKG_DIR, "node", "mi355rt.node")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -64,6 +66,17 @@ def build_scene(force=False):
     return SCENE_LIB
 
 
+def build_tex(force=False):
+    src = os.path.join(CSRC, "texture", "image_decode.cpp")
+    deps = [src] + _headers()
+    if not force and _newer(TEX_LIB, deps):
+        return TEX_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", TEX_LIB, src]
+    subprocess.run(cmd, check=True)
+    return TEX_LIB
+
+
 def build_rt(force=False, extra_flags=()):
     src = os.path.join(CSRC, "rt_api.hip")
     deps = _glob_sources(CSRC, (".hip", ".h", ".hpp")) + _headers()
@@ -84,17 +97,17 @@ def build_node_addon(force=False):
     hdr = "/usr/include/node/node_api.h"
     if not os.path.exists(src) or not os.path.exists(hdr):
         return None
-    if not force and _newer(NODE_ADDON, [src, RT_LIB, SCENE_LIB] + _headers()):
+    if not force and _newer(NODE_ADDON, [src, RT_LIB, SCENE_LIB, TEX_LIB] + _headers()):
         return NODE_ADDON
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I", "/usr/include/node", "-I", INCLUDE,
-           "-o", NODE_ADDON, src, "-L", LIB_DIR, "-lmi355rt", "-lmi355scene",
+           "-o", NODE_ADDON, src, "-L", LIB_DIR, "-lmi355rt", "-lmi355scene", "-lmi355tex",
            "-Wl,-rpath,$ORIGIN/../lib"]
     subprocess.run(cmd, check=True)
     return NODE_ADDON
 
 
 def build_all(force=False):
-    out = {"scene": build_scene(force), "rt": build_rt(force)}
+    out = {"scene": build_scene(force), "tex": build_tex(force), "rt": build_rt(force)}
     try:
         out["node"] = build_node_addon(force)
     except subprocess.CalledProcessError as e:  # the addon is a convenience, not the product path

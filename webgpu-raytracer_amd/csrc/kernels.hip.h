@@ -1973,6 +1973,28 @@ __global__ __launch_bounds__(256) void k_accumulate_frames(DevFrame F, const Dev
   F.accum[p] = acc;
 }
 
+// ===================================================================== texture ingest
+// One 1024 x 1024 layer from a w x h RGBA8 image (ResourceManager.ts:164-196): one thread per destination texel,
+// four source texels each; rows of a wave are contiguous in the destination.  src == nullptr: white fallback bitmap.
+__global__ __launch_bounds__(256) void k_resize_texture(const uint32_t* __restrict__ src, uint32_t w, uint32_t h,
+                                                        uint32_t* __restrict__ dst) {
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+  if (x >= RT_TEX_SIZE || y >= RT_TEX_SIZE) return;
+  uint32_t out = 0xffffffffu;
+  if (src) {
+    uint32_t x0, x1, y0, y1;
+    const float fx = rt_resize_coord(x, w, RT_TEX_SIZE, &x0, &x1);
+    const float fy = rt_resize_coord(y, h, RT_TEX_SIZE, &y0, &y1);
+    const uint32_t c00 = src[(size_t)y0 * w + x0], c10 = src[(size_t)y0 * w + x1];
+    const uint32_t c01 = src[(size_t)y1 * w + x0], c11 = src[(size_t)y1 * w + x1];
+    out = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 32u; k += 8u)
+      out |= rt_bilinear_u8((c00 >> k) & 255u, (c10 >> k) & 255u, (c01 >> k) & 255u, (c11 >> k) & 255u, fx, fy) << k;
+  }
+  dst[(size_t)y * RT_TEX_SIZE + x] = out;
+}
+
 // ===================================================================== post process
 __device__ __forceinline__ rt3 pp_radiance(const DevPost& P, const rt_scene_uniforms& U, int cx, int cy) {  // :41-47
   int x = cx < 0 ? 0 : (cx > (int)U.width - 1 ? (int)U.width - 1 : cx);

@@ -43,7 +43,7 @@ struct rt_ctx {
   std::string error;
 
   // scene buffers (raw bridge layout)
-  DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures;
+  DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
@@ -318,7 +318,8 @@ void rt_destroy(rt_ctx* c) {
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
-                         &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters};
+                         &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
+                         &c->tex_staging};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -390,6 +391,57 @@ int rt_upload_textures(rt_ctx* c, const uint8_t* rgba, uint32_t layers) {
   HIP_TRY(c, hipMemcpyAsync(c->textures.ptr, rgba, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->tex_layers = layers;
+  return RT_OK;
+}
+
+int rt_alloc_texture_layers(rt_ctx* c, uint32_t layers) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (layers == 0) {
+    c->tex_layers = 0;
+    return RT_OK;
+  }
+  const size_t bytes = (size_t)layers * RT_TEX_SIZE * RT_TEX_SIZE * 4;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_buffer(c->textures);
+  int r = ensure_buffer(c, c->textures, bytes, false);
+  if (r < 0) return r;
+  HIP_TRY(c, hipMemsetAsync(c->textures.ptr, 0xff, bytes, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tex_layers = layers;
+  return RT_OK;
+}
+
+int rt_upload_texture_image(rt_ctx* c, uint32_t layer, const uint8_t* rgba, uint32_t width, uint32_t height) {
+  if (!c) return RT_ERR_INVALID;
+  if (layer >= c->tex_layers || !c->textures.ptr) return fail(c, RT_ERR_INVALID, "texture layer out of range");
+  if (rgba && (width == 0 || height == 0 || width > 32768u || height > 32768u))
+    return fail(c, RT_ERR_INVALID, "texture image size out of range");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* dst = (uint32_t*)c->textures.ptr + (size_t)layer * RT_TEX_SIZE * RT_TEX_SIZE;
+  const uint32_t* src = nullptr;
+  if (rgba) {
+    const size_t bytes = (size_t)width * height * 4;
+    int r = ensure_buffer(c, c->tex_staging, bytes, false);
+    if (r < 0) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->tex_staging.ptr, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    src = (const uint32_t*)c->tex_staging.ptr;
+  }
+  hipLaunchKernelGGL(rtk::k_resize_texture, dim3(RT_TEX_SIZE / 256, RT_TEX_SIZE), dim3(256), 0, c->stream, src, width, height,
+                     dst);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free `rgba` and the staging buffer is reused
+  return RT_OK;
+}
+
+int rt_read_texture_layer(rt_ctx* c, uint32_t layer, uint8_t* out, size_t cap) {
+  if (!c || !out) return RT_ERR_INVALID;
+  const size_t bytes = (size_t)RT_TEX_SIZE * RT_TEX_SIZE * 4;
+  if (layer >= c->tex_layers || !c->textures.ptr) return fail(c, RT_ERR_INVALID, "texture layer out of range");
+  if (cap < bytes) return fail(c, RT_ERR_INVALID, "buffer too small for a texture layer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out, (const uint8_t*)c->textures.ptr + (size_t)layer * bytes, bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

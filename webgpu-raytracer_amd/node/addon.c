@@ -4,7 +4,7 @@
  * Here a Node process loads this addon and index.js rebuilds the same class surface on top of it
  * (src/renderer/WebGPURenderer.ts:7-138, src/world-bridge.ts:172-205).  Every function is a thin
  * argument-unpacking wrapper: no rendering logic lives in this file.
- * Build: gcc -shared -fPIC -I/usr/include/node addon.c -L../lib -lmi355rt -lmi355scene -Wl,-rpath,'$ORIGIN/../lib'
+ * Build: gcc -shared -fPIC -I/usr/include/node addon.c -L../lib -lmi355rt -lmi355scene -lmi355tex -Wl,-rpath,'$ORIGIN/../lib'
  */
 #include <node_api.h>
 #include <stdint.h>
@@ -13,6 +13,7 @@
 
 #include "mi355rt.h"
 #include "mi355scene.h"
+#include "mi355tex.h"
 
 #define NAPI_OK(env, call)                                              \
   do {                                                                  \
@@ -293,6 +294,55 @@ static napi_value msGet(napi_env env, napi_callback_info info) {
   NAPI_OK(env, napi_create_typedarray(env, is_u32 ? napi_uint32_array : napi_float32_array, n, ab, 0, &ta));
   return ta;
 }
+static napi_value rtAllocTextureLayers(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  return make_int(env, rt_alloc_texture_layers((rt_ctx*)get_ptr(env, a[0]), get_u32(env, a[1])));
+}
+/* (ctx, layer, rgba | null, width, height) */
+static napi_value rtUploadTextureImage(napi_env env, napi_callback_info info) {
+  napi_value a[5];
+  void* p = NULL;
+  size_t n = 0;
+  if (!get_args(env, info, 5, a) || !get_bytes(env, a[2], &p, &n)) return NULL;
+  const uint32_t w = get_u32(env, a[3]), h = get_u32(env, a[4]);
+  if (p && n < (size_t)w * h * 4) {
+    napi_throw_error(env, NULL, "rtUploadTextureImage: buffer smaller than width * height * 4");
+    return NULL;
+  }
+  return make_int(env, rt_upload_texture_image((rt_ctx*)get_ptr(env, a[0]), get_u32(env, a[1]), (const uint8_t*)p, w, h));
+}
+/* (encoded bytes) -> {data: Uint8Array, width, height}; throws with mt_last_error() when the blob does not decode */
+static napi_value mtDecode(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  void* p = NULL;
+  size_t n = 0;
+  if (!get_args(env, info, 1, a) || !get_bytes(env, a[0], &p, &n)) return NULL;
+  mt_image img;
+  if (mt_decode((const uint8_t*)p, n, &img) != MT_OK) {
+    napi_throw_error(env, NULL, mt_last_error());
+    return NULL;
+  }
+  const size_t bytes = (size_t)img.width * img.height * 4;
+  void* dst = NULL;
+  napi_value ab, ta, obj, w, h;
+  if (napi_create_arraybuffer(env, bytes, &dst, &ab) != napi_ok) {
+    mt_free(&img);
+    napi_throw_error(env, NULL, "mtDecode: allocation failed");
+    return NULL;
+  }
+  memcpy(dst, img.rgba, bytes);
+  const uint32_t iw = img.width, ih = img.height;
+  mt_free(&img);
+  NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+  NAPI_OK(env, napi_create_object(env, &obj));
+  NAPI_OK(env, napi_create_uint32(env, iw, &w));
+  NAPI_OK(env, napi_create_uint32(env, ih, &h));
+  NAPI_OK(env, napi_set_named_property(env, obj, "data", ta));
+  NAPI_OK(env, napi_set_named_property(env, obj, "width", w));
+  NAPI_OK(env, napi_set_named_property(env, obj, "height", h));
+  return obj;
+}
 static napi_value msTextureCount(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -318,7 +368,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     napi_callback fn;
   } table[] = {{"rtCreate", rtCreate}, {"rtDestroy", rtDestroy}, {"rtLastError", rtLastError},
                {"rtSetPipeline", rtSetPipeline}, {"rtResize", rtResize}, {"rtResetAccum", rtResetAccum},
-               {"rtUploadTextures", rtUploadTextures}, {"rtUpload", rtUpload}, {"rtUploadGeometry", rtUploadGeometry},
+               {"rtUploadTextures", rtUploadTextures}, {"rtAllocTextureLayers", rtAllocTextureLayers},
+               {"rtUploadTextureImage", rtUploadTextureImage}, {"mtDecode", mtDecode}, {"rtUpload", rtUpload}, {"rtUploadGeometry", rtUploadGeometry},
                {"rtUploadBVH", rtUploadBVH}, {"rtSetScene", rtSetScene}, {"rtCompute", rtCompute},
                {"rtComputeBatch", rtComputeBatch},
                {"rtPresent", rtPresent}, {"rtSync", rtSync}, {"rtCapture", rtCapture}, {"rtReadAccum", rtReadAccum},

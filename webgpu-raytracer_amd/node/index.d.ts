@@ -42,4 +42,6 @@ export class WorldBridge {
   readonly textureCount: number;
   readonly hasWorld: boolean;
   getTextureRGBA(index: number): Uint8Array | undefined;
+  /** encoded image bytes (PNG), as world-bridge.ts:101-106 hands them out */
+  getTexture(index: number): Uint8Array | undefined;
 }

@@ -9,6 +9,42 @@ const native = require(path.join(__dirname, 'mi355rt.node'));
 const KIND = { topology: 0, instance: 1, lights: 2, draw_commands: 3 };
 const RT_REALLOCATED = 1;
 
+// PNG container (colour type 6, filter 0) around zlib — stands in for the encoded images a glTF would carry
+const zlib = require('zlib');
+const CRC_TABLE = (() => {
+  const t = new Uint32Array(256);
+  for (let i = 0; i < 256; i++) {
+    let c = i;
+    for (let k = 0; k < 8; k++) c = (c & 1) ? (0xedb88320 ^ (c >>> 1)) : (c >>> 1);
+    t[i] = c >>> 0;
+  }
+  return t;
+})();
+function crc32(buf) {
+  let c = 0xffffffff;
+  for (let i = 0; i < buf.length; i++) c = CRC_TABLE[(c ^ buf[i]) & 255] ^ (c >>> 8);
+  return (c ^ 0xffffffff) >>> 0;
+}
+function pngChunk(tag, data) {
+  const out = Buffer.alloc(12 + data.length);
+  out.writeUInt32BE(data.length, 0);
+  out.write(tag, 4, 'latin1');
+  Buffer.from(data.buffer, data.byteOffset, data.length).copy(out, 8);
+  out.writeUInt32BE(crc32(out.subarray(4, 8 + data.length)), 8 + data.length);
+  return out;
+}
+function encodePng(rgba, width, height) {
+  const rows = Buffer.alloc(height * (1 + width * 4));
+  for (let y = 0; y < height; y++)
+    Buffer.from(rgba.buffer, rgba.byteOffset + y * width * 4, width * 4).copy(rows, y * (1 + width * 4) + 1);
+  const ihdr = Buffer.alloc(13);
+  ihdr.writeUInt32BE(width, 0);
+  ihdr.writeUInt32BE(height, 4);
+  ihdr[8] = 8; ihdr[9] = 6;
+  return new Uint8Array(Buffer.concat([Buffer.from([0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a]), pngChunk('IHDR', ihdr),
+    pngChunk('IDAT', zlib.deflateSync(rows, { level: 1 })), pngChunk('IEND', Buffer.alloc(0))]));
+}
+
 class WebGPURenderer {
   // `new WebGPURenderer(canvas)`: the canvas becomes a device ordinal (there is no swap chain).
   constructor(device = 0) {
@@ -37,13 +73,22 @@ class WebGPURenderer {
     this._check(native.rtResize(this._ctx, width, height), 'updateScreenSize');
   }
   resetAccumulation() { this._check(native.rtResetAccum(this._ctx), 'resetAccumulation'); }
+  // ResourceManager.ts:153-198: encoded image per texture -> decode (host) -> 1024x1024 layer (GPU resize);
+  // an image that is missing or does not decode becomes the white fallback bitmap and a warning (:169-175)
   async loadTexturesFromWorld(bridge) {
     const n = bridge.textureCount;
     if (n === 0) { this._check(native.rtUploadTextures(this._ctx, null, 0), 'loadTexturesFromWorld'); return; }
-    const layer = 1024 * 1024 * 4;
-    const all = new Uint8Array(n * layer);
-    for (let i = 0; i < n; i++) all.set(bridge.getTextureRGBA(i), i * layer);
-    this._check(native.rtUploadTextures(this._ctx, all, n), 'loadTexturesFromWorld');
+    this._check(native.rtAllocTextureLayers(this._ctx, n), 'loadTexturesFromWorld');
+    this.textureWarnings = [];
+    for (let i = 0; i < n; i++) {
+      const data = bridge.getTexture(i);
+      let img = null;
+      if (data) {
+        try { img = native.mtDecode(data); } catch (e) { this.textureWarnings.push(`Failed tex ${i}: ${e.message}`); }
+      }
+      this._check(native.rtUploadTextureImage(this._ctx, i, img ? img.data : null, img ? img.width : 0, img ? img.height : 0),
+        'loadTexturesFromWorld');
+    }
   }
   updateBuffer(type, data) {
     return this._check(native.rtUpload(this._ctx, KIND[type], data), `updateBuffer(${type})`) === RT_REALLOCATED;
@@ -119,6 +164,11 @@ class WorldBridge {
   get textureCount() { return this._w ? native.msTextureCount(this._w) : 0; }
   get hasWorld() { return !!this._w && this._cache.vertices.length > 0; }
   getTextureRGBA(i) { return native.msTexture(this._w, i); }
+  // world-bridge.ts:101-106 hands out ENCODED images; the synthetic scenes hold raw texels, so encode them as PNG
+  getTexture(i) {
+    const rgba = this.getTextureRGBA(i);
+    return rgba ? encodePng(rgba, 1024, 1024) : undefined;
+  }
 }
 
 module.exports = { WebGPURenderer, WorldBridge, native };

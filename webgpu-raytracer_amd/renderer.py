@@ -38,6 +38,8 @@ def load_library(path=None):
         "rt_create": (vp, [i32]), "rt_destroy": (None, [vp]), "rt_last_error": (ctypes.c_char_p, [vp]),
         "rt_set_pipeline": (i32, [vp, u32, u32]), "rt_resize": (i32, [vp, u32, u32]),
         "rt_reset_accum": (i32, [vp]), "rt_upload_textures": (i32, [vp, vp, u32]),
+        "rt_alloc_texture_layers": (i32, [vp, u32]), "rt_upload_texture_image": (i32, [vp, u32, vp, u32, u32]),
+        "rt_read_texture_layer": (i32, [vp, u32, vp, ctypes.c_size_t]),
         "rt_upload": (i32, [vp, i32, vp, ctypes.c_size_t]),
         "rt_upload_geometry": (i32, [vp, vp, vp, vp, u32]),
         "rt_upload_bvh": (i32, [vp, vp, u32, vp, u32]),
@@ -68,6 +70,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     "rt_create rt_destroy rt_last_error rt_set_pipeline rt_resize rt_reset_accum rt_upload_textures rt_upload "
+    "rt_alloc_texture_layers rt_upload_texture_image rt_read_texture_layer "
     "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_compute_batch rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum "
@@ -121,12 +124,45 @@ class WebGPURenderer:
         self._check(self.L.rt_reset_accum(self.ctx), "resetAccumulation")
 
     def loadTexturesFromWorld(self, bridge):
+        """ResourceManager.ts:153-198: no textures -> default white texture; otherwise one 1024x1024 layer per
+        encoded image of the bridge — decoded on the host (mi355tex), resized on the GPU — and the white fallback
+        bitmap for an image that is missing or does not decode (the reference warns and carries on, :169-175)."""
         n = bridge.textureCount
         if n == 0:
             self._check(self.L.rt_upload_textures(self.ctx, None, 0), "loadTexturesFromWorld")
             return
-        layers = np.ascontiguousarray(np.stack([bridge.getTextureRGBA(i) for i in range(n)]), dtype=np.uint8)
-        self._check(self.L.rt_upload_textures(self.ctx, _ptr(layers), n), "loadTexturesFromWorld")
+        from . import textures
+        self._check(self.L.rt_alloc_texture_layers(self.ctx, n), "loadTexturesFromWorld")
+        self.texture_warnings = []
+        for i in range(n):
+            data = bridge.getTexture(i)
+            img = None
+            if data is not None:
+                try:
+                    img = textures.decode_image(data)
+                except textures.ImageDecodeError as e:
+                    self.texture_warnings.append("Failed tex %d: %s" % (i, e))
+            self.uploadTextureImage(i, img)
+
+    def uploadTextureImage(self, layer, rgba):
+        """One layer from an (h, w, 4) uint8 image of any size (GPU bilinear resize); None = white fallback."""
+        if rgba is None:
+            self._check(self.L.rt_upload_texture_image(self.ctx, layer, None, 0, 0), "uploadTextureImage")
+            return
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise RendererError("uploadTextureImage expects an (h, w, 4) uint8 array")
+        self._check(self.L.rt_upload_texture_image(self.ctx, layer, _ptr(a), a.shape[1], a.shape[0]), "uploadTextureImage")
+
+    def loadTextureLayers(self, layers):
+        """Already decoded and resized (n, 1024, 1024, 4) uint8 layers (rt_upload_textures)."""
+        a = np.ascontiguousarray(layers, dtype=np.uint8)
+        self._check(self.L.rt_upload_textures(self.ctx, _ptr(a), a.shape[0]), "loadTextureLayers")
+
+    def readTextureLayer(self, layer):
+        out = np.empty((1024, 1024, 4), dtype=np.uint8)
+        self._check(self.L.rt_read_texture_layer(self.ctx, layer, _ptr(out), out.nbytes), "readTextureLayer")
+        return out
 
     def updateBuffer(self, kind, data):
         a = np.ascontiguousarray(data)

@@ -54,6 +54,7 @@ class WorldBridge:
         self._lib = _load()
         self._world = None
         self._cache = {}
+        self._tex_blobs = {}
         self.hasNewData = False
         self.hasNewGeometry = False
         self._last_wh = (-1, -1)
@@ -76,6 +77,7 @@ class WorldBridge:
         if not w:
             raise ValueError(self._lib.ms_last_error().decode())
         self._world = w
+        self._tex_blobs = {}
         self._last_wh = (-1, -1)
         self._refresh()
         self.hasNewData = True
@@ -132,9 +134,21 @@ class WorldBridge:
     def textureCount(self):
         return int(self._lib.ms_world_texture_count(self._world)) if self._world else 0
 
+    def getTexture(self, index):
+        """Encoded image bytes of texture `index` (world-bridge.ts:101-106, `World::get_texture_ptr/_len`
+        lib.rs:359-381).  The synthetic scenes only hold raw texels, so the blob is their PNG encoding (cached)."""
+        if index in self._tex_blobs:
+            return self._tex_blobs[index]
+        rgba = self.getTextureRGBA(index)
+        if rgba is None:
+            return None
+        from .textures import encode_png
+        blob = encode_png(rgba)
+        self._tex_blobs[index] = blob
+        return blob
+
     def getTextureRGBA(self, index):
-        """Decoded 1024x1024 RGBA8 layer (synthetic scenes). The reference returns encoded
-        image bytes (world-bridge.ts:101-106) and lets the browser decode; decoding is out of scope."""
+        """Decoded 1024x1024 RGBA8 layer (synthetic scenes): what decoding + resizing getTexture(index) yields."""
         p = self._lib.ms_world_texture_rgba(self._world, index)
         if not p:
             return None
