@@ -40,6 +40,22 @@ const char* ms_last_error(void);
  * lights and draw commands. (No animations exist without glTF; time is accepted
  * for signature parity.) */
 void ms_world_update(ms_world* w, float time);
+
+/* World::new(scene_name, mesh_obj_source, glb_data) with a glTF 2.0 binary (or JSON with base64 data URIs) — lib.rs:45-102
+ * + loader.rs:7-354: geometries (one per mesh primitive), instances, nodes, skins, animations and
+ * encoded textures are appended to the named procedural scene ("viewer": the Cornell-style room without the dummy
+ * sphere).  A GLB that does not parse leaves the procedural scene alone, like the reference's `let _ = load_gltf(..)`;
+ * ms_last_error() then says why.  ms_world_update(t) samples the active animation at t (looping), recomputes the
+ * scene graph's global transforms, skins every skinned geometry on the CPU and rebuilds BLAS / TLAS (lib.rs:149-270,
+ * rebuilder.rs:36-91). */
+ms_world* ms_world_create_glb(const char* scene_name, const char* obj_source, const uint8_t* glb, size_t glb_size);
+/* get_animation_count / get_animation_name / set_animation / load_animation_glb — lib.rs:106-147.
+ * load_animation_glb appends the animations of another GLB (returns how many, or -1). */
+size_t ms_world_animation_count(const ms_world* w);
+const char* ms_world_animation_name(const ms_world* w, size_t index);
+void ms_world_set_animation(ms_world* w, size_t index);
+int ms_world_load_animation_glb(ms_world* w, const uint8_t* glb, size_t glb_size);
+size_t ms_world_node_count(const ms_world* w);
 /* World::update_camera(width, height) lib.rs:347-352. */
 void ms_world_update_camera(ms_world* w, float width, float height);
 
@@ -61,6 +77,10 @@ const float* ms_world_camera(const ms_world* w, size_t* len);           /* 24 f3
  * provide already-decoded RGBA8 1024x1024 layers instead. */
 size_t ms_world_texture_count(const ms_world* w);
 const uint8_t* ms_world_texture_rgba(const ms_world* w, size_t index); /* 1024*1024*4 bytes */
+/* get_texture_count / get_texture_ptr / get_texture_size for a glTF input (lib.rs:350-369): the ENCODED image bytes of
+ * each glTF texture, in texture order; size 0 = external or missing image (the renderer substitutes the white layer). */
+size_t ms_world_encoded_texture_count(const ms_world* w);
+const uint8_t* ms_world_encoded_texture(const ms_world* w, size_t index, size_t* size);
 
 #ifdef __cplusplus
 }

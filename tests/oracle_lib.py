@@ -110,7 +110,28 @@ class OracleRenderer:
         n = bridge.textureCount
         if n == 0:
             return
-        layers = np.ascontiguousarray(np.stack([bridge.getTextureRGBA(i) for i in range(n)]), dtype=np.uint8)
+        layers = []
+        for i in range(n):
+            layer = bridge.getTextureRGBA(i)
+            if layer is None:
+                # encoded image (glTF input): the checker decodes with PIL (independent of the product's decoder) and
+                # resizes with the oracle's restatement of the rule; missing / undecodable -> white fallback layer
+                layer = np.empty((1024, 1024, 4), np.uint8)
+                src = None
+                blob = bridge.getTexture(i)
+                if blob:
+                    try:
+                        import io
+                        from PIL import Image
+                        src = np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(blob)).convert("RGBA")))
+                    except Exception:
+                        src = None
+                if src is None:
+                    self.L.oracle_resize_texture(None, 0, 0, _ptr(layer))
+                else:
+                    self.L.oracle_resize_texture(_ptr(src), src.shape[1], src.shape[0], _ptr(layer))
+            layers.append(layer)
+        layers = np.ascontiguousarray(np.stack(layers), dtype=np.uint8)
         self.L.oracle_upload_textures(self.ctx, _ptr(layers), n)
 
     def updateBuffer(self, kind, data):

@@ -1,0 +1,301 @@
+"""glTF / GLB input of the scene compiler (reference: rust-shader-tools/src/loader.rs, lib.rs:45-270,
+rebuilder.rs:36-91).  The reference has no asset and no test for this path and its parser is an un-vendored crate, so the
+checker is the numpy restatement in tests/gltf_util.py (parity unpinned) — plus GPU = oracle on the resulting arrays."""
+import io
+
+import numpy as np
+import pytest
+
+import gltf_util as G
+
+f32 = np.float32
+ENV_VERTS = 24      # the viewer room: 6 quads (procedural.rs:634-791)
+
+
+def quad_mesh():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], f32)
+    nrm = np.tile(np.array([0, 0, 1], f32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], f32)
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    return pos, nrm, uv, idx
+
+
+def png_blob(W, h=8, w=16, seed=0):
+    rng = np.random.default_rng(seed)
+    return W.textures.encode_png(rng.integers(0, 256, (h, w, 4), dtype=np.uint8))
+
+
+def build_static(W):
+    b = G.GltfBuilder()
+    pos, nrm, uv, idx = quad_mesh()
+    inter = np.concatenate([pos, nrm], axis=1).astype(f32)            # interleaved POSITION | NORMAL, stride 24
+    v = b.view(inter.tobytes(), stride=24)
+    a_pos = b.accessor(pos, G.F32, "VEC3", view=v, offset=0, count=4, minmax=True)
+    a_nrm = b.accessor(nrm, G.F32, "VEC3", view=v, offset=12, count=4)
+    a_uv = b.accessor((uv * 65535).astype(np.uint16), G.U16, "VEC2", normalized=True)
+    a_idx = b.accessor(idx, G.U16, "SCALAR")
+    tri = np.array([[0, 0, 1], [0.5, 0, 1], [0, 0.5, 1]], f32)
+    a_tri = b.accessor(tri, G.F32, "VEC3", minmax=True)
+    lpos = pos * f32(0.25) + f32(0.5)
+    a_lpos = b.accessor(lpos, G.F32, "VEC3", minmax=True)
+    a_lidx = b.accessor(idx.astype(np.uint8), G.U8, "SCALAR")
+    t0 = b.image_texture(png_blob(W))
+    t1 = b.external_texture()
+    b.doc["materials"] = [
+        {"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.5,
+                                  "baseColorTexture": {"index": t0}}, "normalTexture": {"index": t1}},
+        {"pbrMetallicRoughness": {"metallicFactor": 0.0}, "emissiveFactor": [5.0, 5.0, 5.0], "occlusionTexture": {"index": t0}},
+    ]
+    b.doc["meshes"] = [{"primitives": [
+        {"attributes": {"POSITION": a_pos, "NORMAL": a_nrm, "TEXCOORD_0": a_uv}, "indices": a_idx, "material": 0},
+        {"attributes": {"POSITION": a_tri}},                                                   # no indices, normals, uv, material
+        {"attributes": {"POSITION": a_lpos}, "indices": a_lidx, "material": 1, "mode": 4},
+        {"attributes": {"POSITION": a_tri}, "mode": 1},                                        # LINES: not consumed
+    ]}]
+    b.doc["nodes"] = [{"name": "root", "translation": [0.1, 0.2, 0.3], "children": [1]},
+                      {"name": "model", "mesh": 0, "rotation": [0, 0.258819, 0, 0.9659258], "scale": [1, 2, 1]}]
+    b.doc["scenes"][0]["nodes"] = [0]
+    return b, dict(pos=pos, nrm=nrm, uv=uv, tri=tri, lpos=lpos)
+
+
+def rows_of_geometry(bridge, gi):
+    topo = np.asarray(bridge.mesh_topology).reshape(-1, 20)
+    return topo[topo[:, 3] == gi]
+
+
+def test_static_glb_geometry_materials_textures(W):
+    b, ref = build_static(W)
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=b.glb())
+    assert br.loadWarning == ""
+    assert br.nodeCount == 2 and br.getAnimationList() == []
+    v = np.asarray(br.vertices).reshape(-1, 4)
+    n = np.asarray(br.normals).reshape(-1, 4)
+    uv = np.asarray(br.uvs).reshape(-1, 2)
+    assert len(v) == ENV_VERTS + 4 + 3 + 4        # no placeholder sphere when a GLB is given
+    assert np.array_equal(v[ENV_VERTS:, :3], np.concatenate([ref["pos"], ref["tri"], ref["lpos"]])) and (v[:, 3] == 1).all()
+    assert np.array_equal(n[ENV_VERTS:ENV_VERTS + 4, :3], ref["nrm"])
+    assert (n[ENV_VERTS + 4:, :3] == np.array([0, 1, 0], f32)).all()          # default normal
+    want_uv = ((ref["uv"] * 65535).astype(np.uint16).astype(f32) / f32(65535))
+    assert np.array_equal(uv[ENV_VERTS:ENV_VERTS + 4], want_uv) and (uv[ENV_VERTS + 4:] == 0).all()
+    # geometries: 0 env, 1 (empty) OBJ slot, 2.. one per consumed primitive
+    r2, r3, r4 = (rows_of_geometry(br, g) for g in (2, 3, 4))
+    assert len(r2) == 2 and len(r3) == 1 and len(r4) == 2 and len(rows_of_geometry(br, 5)) == 0
+    a2 = r2[0, 4:].view(f32)
+    assert np.allclose(a2[:3], [0.2, 0.4, 0.6]) and a2[3] == 0 and a2[4] == 0 and a2[5] == 0.5 and a2[6] == 1.5   # LAMBERTIAN
+    assert list(a2[8:12]) == [0, -1, 1, -1] and list(a2[12:16]) == [0, 0, 0, -1]
+    a3 = r3[0, 4:].view(f32)
+    assert list(a3[:8]) == [1, 1, 1, 1, 1, 1, 1.5, 0] and list(a3[8:12]) == [-1] * 4          # default material -> METAL
+    a4 = r4[0, 4:].view(f32)
+    assert a4[3] == 3 and list(a4[12:16]) == [5, 5, 5, 0]                                       # emissive -> LIGHT, occlusion tex 0
+    # indices are global vertex ids
+    assert sorted(set(r2[:, :3].ravel())) == [ENV_VERTS + k for k in range(4)]
+    assert sorted(r3[0, :3]) == [ENV_VERTS + 4, ENV_VERTS + 5, ENV_VERTS + 6]
+    # instances: env + one per primitive; lib.rs:196-204 overwrites every instance after the first
+    inst = np.asarray(br.instances).reshape(-1, 36)
+    assert len(inst) == 4 and sorted(inst[:, 34].view(np.uint32)) == [0, 2, 3, 4]
+    hack = np.array([[-0.7, 0, 0, 0], [0, 0.7, 0, 0], [0, 0, -0.7, 0], [0, 0, 0, 1]], f32)
+    for row in inst:
+        m = row[:16].reshape(4, 4).T
+        if row[34:35].view(np.uint32)[0] == 0:
+            assert np.array_equal(m, np.eye(4, dtype=f32))
+        else:
+            assert np.allclose(m, hack, atol=1e-6)
+    # lights: the room's light quad + the emissive primitive
+    lights = np.asarray(br.lights).reshape(-1, 2)
+    assert len(lights) == 2 + 2
+    # textures: encoded blobs in glTF texture order; an external image is an empty blob
+    assert br.textureCount == 2
+    assert br.getTexture(0) == png_blob(W) and br.getTexture(1) is None and br.getTextureRGBA(0) is None
+
+
+def build_skinned(W, matrix_joint=False, weights_u8=False):
+    b = G.GltfBuilder()
+    ys = np.linspace(0, 1, 7, dtype=f32)
+    pos = np.array([[x, y, 0] for y in ys for x in (-0.1, 0.1)], f32)
+    nrm = np.tile(np.array([0, 0, 1], f32), (len(pos), 1))
+    idx = []
+    for k in range(len(ys) - 1):
+        a = 2 * k
+        idx += [a, a + 1, a + 3, a, a + 3, a + 2]
+    w1 = np.clip((pos[:, 1] - 0.25) * 2, 0, 1).astype(f32)
+    weights = np.stack([1 - w1, w1, np.zeros_like(w1), np.zeros_like(w1)], 1).astype(f32)
+    joints = np.tile(np.array([0, 1, 0, 0], np.uint8), (len(pos), 1))
+    a_pos = b.accessor(pos, G.F32, "VEC3", minmax=True)
+    a_nrm = b.accessor(nrm, G.F32, "VEC3")
+    a_idx = b.accessor(np.array(idx, np.uint32), G.U32, "SCALAR")
+    a_j = b.accessor(joints, G.U8, "VEC4")
+    if weights_u8:
+        wq = np.round(weights * 255).astype(np.uint8)
+        a_w = b.accessor(wq, G.U8, "VEC4", normalized=True)
+        weights = wq.astype(f32) / f32(255)
+    else:
+        a_w = b.accessor(weights, G.F32, "VEC4")
+    ibm = np.stack([np.eye(4, dtype=f32), np.eye(4, dtype=f32)])
+    ibm[1][1, 3] = -0.5                                       # inverse of translate(0, 0.5, 0)
+    a_ibm = b.accessor(np.stack([m.T for m in ibm]), G.F32, "MAT4")        # column-major
+    b.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": a_pos, "NORMAL": a_nrm, "JOINTS_0": a_j, "WEIGHTS_0": a_w},
+                                        "indices": a_idx}]}]
+    j1 = {"name": "j1", "translation": [0, 0.5, 0]}
+    if matrix_joint:
+        j1 = {"name": "j1", "matrix": G.mat_from_srt([1, 1, 1], [0, 0, 0, 1], [0, 0.5, 0]).T.reshape(-1).tolist()}
+    b.doc["nodes"] = [{"name": "body", "mesh": 0, "skin": 0}, {"name": "j0", "children": [2]}, j1]
+    b.doc["skins"] = [{"joints": [1, 2], "inverseBindMatrices": a_ibm}]
+    b.doc["scenes"][0]["nodes"] = [0, 1]
+    # animation 0: rotation of j1 (LINEAR), translation of j0 (STEP), scale of j1 (CUBICSPLINE)
+    c60, s60 = np.cos(np.pi / 6), np.sin(np.pi / 6)
+    t_rot = b.accessor(np.array([0, 0.5, 1.0], f32), G.F32, "SCALAR", minmax=True)
+    v_rot = b.accessor(np.array([[0, 0, 0, 1], [0, 0, s60, c60], [0, 0, 0, 1]], f32), G.F32, "VEC4")
+    t_tr = b.accessor(np.array([0, 0.5], f32), G.F32, "SCALAR", minmax=True)
+    v_tr = b.accessor(np.array([[0, 0, 0], [0.2, 0, 0]], f32), G.F32, "VEC3")
+    t_sc = b.accessor(np.array([0, 1.0], f32), G.F32, "SCALAR", minmax=True)
+    sc = np.array([[0, 0, 0], [1, 1, 1], [0, 0, 0], [0, 0, 0], [1.5, 1, 1], [0, 0, 0]], f32)     # (in, value, out) x 2 keys
+    v_sc = b.accessor(sc, G.F32, "VEC3")
+    b.doc["animations"] = [{"name": "bend", "samplers": [
+        {"input": t_rot, "output": v_rot, "interpolation": "LINEAR"},
+        {"input": t_tr, "output": v_tr, "interpolation": "STEP"},
+        {"input": t_sc, "output": v_sc, "interpolation": "CUBICSPLINE"}],
+        "channels": [{"sampler": 0, "target": {"node": 2, "path": "rotation"}},
+                     {"sampler": 1, "target": {"node": 1, "path": "translation"}},
+                     {"sampler": 2, "target": {"node": 2, "path": "scale"}}]},
+        {"samplers": [{"input": t_tr, "output": v_tr}], "channels": [{"sampler": 0, "target": {"node": 1, "path": "translation"}}]}]
+    anim = dict(rot=([0, 0.5, 1.0], [[0, 0, 0, 1], [0, 0, s60, c60], [0, 0, 0, 1]]), tr=([0, 0.5], [[0, 0, 0], [0.2, 0, 0]]),
+                sc=([0, 1.0], sc), duration=1.0)
+    return b, dict(pos=pos, nrm=nrm, joints=joints.astype(int), weights=weights, ibm=ibm, anim=anim)
+
+
+def fresh_nodes():
+    return [dict(t=[0, 0, 0], r=[0, 0, 0, 1], s=[1, 1, 1]), dict(t=[0, 0, 0], r=[0, 0, 0, 1], s=[1, 1, 1], children=[2]),
+            dict(t=[0, 0.5, 0], r=[0, 0, 0, 1], s=[1, 1, 1])]
+
+
+def expected_skinned(ref, t, nodes, anim_index=0):
+    """`nodes` carries the local TRS from update to update: the reference animates the nodes in place and a channel that
+    the active animation does not have keeps its last value (lib.rs:383-491)."""
+    a = ref["anim"]
+    if anim_index == 0:
+        dur = a["duration"]
+        tt = float(np.fmod(f32(t), f32(dur))) if dur > 0.001 else 0.0
+        p, n, fac = G.sample_channel(a["rot"][0], a["rot"][1], "LINEAR", dur, tt)
+        nodes[2]["r"] = G.quat_slerp(G.quat_normalize(p), G.quat_normalize(n), fac)
+        p, n, fac = G.sample_channel(a["tr"][0], a["tr"][1], "STEP", dur, tt)
+        nodes[1]["t"] = p + (n - p) * fac
+        p, n, fac = G.sample_channel(a["sc"][0], a["sc"][1], "CUBICSPLINE", dur, tt)
+        nodes[2]["s"] = p + (n - p) * fac
+    else:
+        dur = 0.5
+        tt = float(np.fmod(f32(t), f32(dur)))
+        p, n, fac = G.sample_channel(a["tr"][0], a["tr"][1], "LINEAR", dur, tt)
+        nodes[1]["t"] = p + (n - p) * fac
+    g = G.node_globals(nodes)
+    jm = [(g[1] @ ref["ibm"][0]).astype(f32), (g[2] @ ref["ibm"][1]).astype(f32)]
+    return G.skin_vertices(ref["pos"], ref["nrm"], ref["joints"], ref["weights"], jm)
+
+
+@pytest.mark.parametrize("matrix_joint,weights_u8", [(False, False), (True, False), (False, True)])
+def test_skinned_animated_glb_follows_the_restatement(W, matrix_joint, weights_u8):
+    b, ref = build_skinned(W, matrix_joint, weights_u8)
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=b.glb())
+    assert br.loadWarning == "" and br.nodeCount == 3
+    assert br.getAnimationList() == ["bend", "anim"]           # unnamed animations are called "anim" (loader.rs:347)
+    nodes = fresh_nodes()
+    expected_skinned(ref, 0.0, nodes)                          # World::new ends with update(0.0)
+    for t in (0.0, 0.2, 0.5, 0.77, 1.3, 2.0):
+        br.update(t)
+        v = np.asarray(br.vertices).reshape(-1, 4)[ENV_VERTS:, :3]
+        n = np.asarray(br.normals).reshape(-1, 4)[ENV_VERTS:, :3]
+        wp, wn = expected_skinned(ref, t, nodes)
+        assert np.allclose(v, wp, atol=2e-6), (t, np.abs(v - wp).max())
+        assert np.allclose(n, wn, atol=2e-6)
+    # the skinned instance sits at identity before the i > 0 overwrite; BLAS follows the deformation
+    br.update(0.5)
+    expected_skinned(ref, 0.5, nodes)
+    blas = np.asarray(br.blas).reshape(-1, 8)
+    inst = np.asarray(br.instances).reshape(-1, 36)
+    model = [r for r in inst if r[34:35].view(np.uint32)[0] == 2][0]
+    root = blas[int(model[32:33].view(np.uint32)[0])]
+    v = np.asarray(br.vertices).reshape(-1, 4)[ENV_VERTS:, :3]
+    assert np.allclose(root[:3], v.min(0), atol=1e-5) and np.allclose(root[4:7], v.max(0), atol=1e-5)   # (flat boxes are padded)
+    # second animation (default LINEAR sampler), switched with setAnimation
+    br.setAnimation(1)
+    br.update(0.25)
+    v = np.asarray(br.vertices).reshape(-1, 4)[ENV_VERTS:, :3]
+    assert np.allclose(v, expected_skinned(ref, 0.25, nodes, anim_index=1)[0], atol=2e-6)   # j1 keeps its pose of t = 0.5
+    # load_animation_glb appends the other file's animations (lib.rs:126-147)
+    assert br.loadAnimation(b.glb()) == 2 and len(br.getAnimationList()) == 4
+    assert br.loadAnimation(b"garbage") == -1 and len(br.getAnimationList()) == 4
+
+
+def test_json_document_with_data_uri_and_sparse_accessor(W):
+    b = G.GltfBuilder()
+    pos, nrm, uv, idx = quad_mesh()
+    a_pos = b.accessor(pos, G.F32, "VEC3", minmax=True)
+    a_idx = b.accessor(idx, G.U16, "SCALAR")
+    sp_i = b.view(np.array([1, 3], np.uint16).tobytes())
+    sp_v = b.view(np.array([[2, 0, 0], [0, 3, 0]], f32).tobytes())
+    b.doc["accessors"][a_pos]["sparse"] = {"count": 2, "indices": {"bufferView": sp_i, "componentType": G.U16},
+                                            "values": {"bufferView": sp_v}}
+    b.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": a_pos}, "indices": a_idx}]}]
+    b.doc["nodes"] = [{"mesh": 0}]
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=b.gltf_json())
+    assert br.loadWarning == ""
+    v = np.asarray(br.vertices).reshape(-1, 4)[ENV_VERTS:, :3]
+    want = pos.copy()
+    want[1], want[3] = [2, 0, 0], [0, 3, 0]
+    assert np.array_equal(v, want)
+
+
+def test_broken_glb_leaves_the_procedural_scene(W):
+    b, _ = build_static(W)
+    glb = b.glb()
+    plain = W.WorldBridge()
+    plain.loadScene("viewer")
+    for bad in (glb[:40], b"glTF" + b"\0" * 30, b"{not json", glb[:20] + b"\xff" * 8 + glb[28:]):
+        br = W.WorldBridge()
+        br.loadScene("viewer", glbData=bad)
+        assert br.loadWarning != ""
+        # like the reference (lib.rs:57-67 ignores the loader's error): the room alone, without the placeholder sphere
+        assert len(br.vertices) // 4 == ENV_VERTS and br.textureCount == 0 and br.getAnimationList() == []
+        assert np.array_equal(np.asarray(br.vertices), np.asarray(plain.vertices)[:ENV_VERTS * 4])
+
+
+@pytest.mark.gpu
+def test_animated_textured_glb_renders_like_the_oracle(W, oracle_lib):
+    PIL = pytest.importorskip("PIL.Image")
+    b, _ = build_skinned(W)
+    rng = np.random.default_rng(5)
+    tex = (rng.integers(0, 256, (40, 60, 3), dtype=np.uint8) // 2 + 100).astype(np.uint8)
+    jpg = io.BytesIO()
+    PIL.fromarray(tex, "RGB").save(jpg, "JPEG", quality=90)
+    t0 = b.image_texture(jpg.getvalue(), "image/jpeg")
+    t1 = b.external_texture()
+    uvs = np.stack([np.tile([0.0, 1.0], 7), np.repeat(np.linspace(0, 1, 7), 2)], 1).astype(f32)
+    b.doc["meshes"][0]["primitives"][0]["attributes"]["TEXCOORD_0"] = b.accessor(uvs, G.F32, "VEC2")
+    b.doc["materials"] = [{"pbrMetallicRoughness": {"metallicFactor": 0.0, "baseColorTexture": {"index": t0}},
+                           "emissiveTexture": {"index": t1}}]
+    b.doc["meshes"][0]["primitives"][0]["material"] = 0
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=b.glb())
+    assert br.textureCount == 2
+    images = []
+    for t in (0.0, 0.3):
+        br.update(t)
+        gpu, cpu = W.WebGPURenderer(0), oracle_lib.OracleRenderer()
+        for r in (gpu, cpu):
+            r.buildPipeline(6, 1)
+            W.upload_scene(r, br, 96, 64)
+            for f in (1, 2, 3):
+                r.compute(f)
+            r.present()
+        gpu.sync()
+        assert gpu.texture_warnings == []
+        assert np.array_equal(gpu.readTextureLayer(1), np.full((1024, 1024, 4), 255, np.uint8))     # external image -> white
+        assert np.array_equal(gpu.readAccum().view(np.uint32), cpu.readAccum().view(np.uint32))
+        assert np.array_equal(gpu.captureFrame()["data"], cpu.captureFrame()["data"])
+        gc, cc = gpu.getCounters(), cpu.getCounters()
+        assert all(gc[k] == cc[k] for k in ("primary_rays", "extension_rays", "shadow_rays"))
+        images.append(gpu.readAccum().copy())
+        gpu.destroy()
+    assert not np.array_equal(images[0], images[1])          # the pose changed the picture

@@ -5,8 +5,12 @@ OUT=$R/gpurun_out/profiles_r01
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command itself
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/r01_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+grep -c '"metric"' $OUT/r01_bench_under_rocprof.json || tail -5 $OUT/bench_under_rocprof.err
 cp $OUT/bench_trace/*/*_kernel_stats.csv $OUT/r01_bench_kernel_stats.csv
+# 1b. the wavefront form on the largest 1080p config (sponza-like, 263k triangles), 16 frames in batches of 8
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wf_trace -- python3 $R/tools/prof_frames.py sponza_like 1920 1080 16 8 3 0 1 8 > $OUT/wf_trace.log 2>&1
+cp $OUT/wf_trace/*/*_kernel_stats.csv $OUT/r01_sponza_wavefront_kernel_stats.csv
 # 2. PMC passes on the same workload: 64 frames as two batched dispatches of 32 (counters in their own runs)
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES SQ_LDS_BANK_CONFLICT" \
@@ -30,5 +34,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   python3 $R/tools/pmc_summary.py $OUT/post_$set | grep postprocess >> $OUT/r01_pmc_summary.txt
 done
 cat $OUT/r01_pmc_summary.txt | grep -v prepare
-tail -1 $OUT/bench_under_rocprof.log | cut -c1-300
-rm -rf $OUT/bench_trace $OUT/pmc_* $OUT/post_*
+cut -c1-300 $OUT/r01_bench_under_rocprof.json
+rm -rf $OUT/bench_trace $OUT/wf_trace $OUT/pmc_* $OUT/post_*

@@ -114,6 +114,16 @@ inline V3 m4_transform_point3(const M4& m, V3 p) {
   }
   return v3(r[0], r[1], r[2]);
 }
+inline V3 m4_transform_vector3(const M4& m, V3 p) {  // glam Mat4::transform_vector3: w = 0
+  float r[3];
+  for (int i = 0; i < 3; i++) {
+    float acc = m.c[0][i] * p.x;
+    acc = m.c[1][i] * p.y + acc;
+    acc = m.c[2][i] * p.z + acc;
+    r[i] = acc;
+  }
+  return v3(r[0], r[1], r[2]);
+}
 // General 4x4 inverse by 2x2 sub-determinant factors (the GLM/glam scalar path).
 M4 m4_inverse(const M4& m) {
   const float m00 = m.c[0][0], m01 = m.c[0][1], m02 = m.c[0][2], m03 = m.c[0][3];
@@ -285,16 +295,26 @@ ObjMesh parse_obj(const std::string& source) {
 }
 
 // -------------------------------------------------------------- geometry
-struct Geometry {  // geometry.rs:6-25 (skinning fields dropped: no glTF input)
-  std::vector<V3> positions, normals;
+struct Geometry {  // geometry.rs:6-25
+  std::vector<V3> positions, normals;  // base_positions / base_normals (the skinning input)
   std::vector<V2> uvs;
   std::vector<uint32_t> indices;
   std::vector<float> attributes;  // 16 f32 per triangle
+  std::vector<uint32_t> joints;   // 4 per vertex
+  std::vector<float> weights;     // 4 per vertex
+  long skin_index = -1;           // Option<usize>
 
-  uint32_t push_vertex(V3 p, V3 n, V2 uv) {
+  uint32_t push_vertex(V3 p, V3 n, V2 uv) {  // geometry.rs:33-45
+    const uint32_t j[4] = {0, 0, 0, 0};
+    const float w[4] = {0, 0, 0, 0};
+    return push_vertex_skinned(p, n, uv, j, w);
+  }
+  uint32_t push_vertex_skinned(V3 p, V3 n, V2 uv, const uint32_t j[4], const float w[4]) {  // geometry.rs:47-66
     positions.push_back(p);
     normals.push_back(n);
     uvs.push_back(uv);
+    joints.insert(joints.end(), j, j + 4);
+    weights.insert(weights.end(), w, w + 4);
     return (uint32_t)positions.size() - 1;
   }
   // geometry.rs:68-103
@@ -443,8 +463,11 @@ struct SceneData {
   std::vector<Geometry> geometries;
   std::vector<SceneInstance> instances;
   std::vector<std::vector<uint8_t>> textures_rgba;  // decoded 1024x1024 RGBA8 layers (synthetic scenes only)
+  std::vector<std::vector<uint8_t>> textures;       // encoded image bytes, one per glTF texture (SceneData.textures)
   bool keep_instance_transforms = false;            // synthetic scenes bypass lib.rs:196-204
 };
+
+#include "gltf_loader.h"
 
 // scene/camera.rs:14-56
 void camera_buffer(const CameraConfig& c, float aspect, float out[24]) {
@@ -581,13 +604,13 @@ SceneData scene_mesh() {
 }
 
 // procedural.rs:634-791
-SceneData scene_viewer(const ObjMesh* mesh) {
+SceneData scene_viewer(const ObjMesh* mesh, bool has_glb) {
   Geometry env, model;
   add_cornell_shell(env, CornellStyle{METAL, 0.15f, v3(10, 10, 10), 150, 150, 405, 405});
   if (mesh) {
     add_mesh_instance(model, *mesh, v3(0, 1, 0), 1.0f, 0.0f, v3(0.8f, 0.8f, 0.8f), LAMBERTIAN, 0.0f, -1.0f);
-  } else {
-    add_sphere(model, v3(0, 1, 0), 0.5f, v3(1, 0, 1), LAMBERTIAN, 0.0f, -1.0f);  // placeholder
+  } else if (!has_glb) {
+    add_sphere(model, v3(0, 1, 0), 0.5f, v3(1, 0, 1), LAMBERTIAN, 0.0f, -1.0f);  // placeholder (no OBJ, no GLB)
   }
   SceneData sd;
   sd.camera = CameraConfig{v3(0, 1, -3.9f), v3(0, 1, 0), v3(0, 1, 0), 40.0f, 0.0f, 3.9f};
@@ -1031,11 +1054,86 @@ struct ms_world {
   // bridge arrays (render_buffers.rs:6-17)
   std::vector<float> vertices, normals, uvs, tlas, blas, instances, camera;
   std::vector<uint32_t> topology, lights, draw_commands;
+  // glTF scene graph (SceneData.nodes / skins / animations) and World.active_anim_index
+  GltfScene gltf;
+  size_t active_anim = 0;
 };
 
 static thread_local std::string g_last_error;
 
-static void world_update(ms_world& w) {
+// lib.rs:383-491 apply_animation: sample every channel of one animation at `time` into the nodes' local TRS
+static void apply_animation(ms_world& w, size_t anim_idx, float time_in) {
+  const GAnimation& anim = w.gltf.animations[anim_idx];
+  for (const GChannel& ch : anim.channels) {
+    if (ch.target_node >= w.gltf.nodes.size()) continue;
+    const float time = anim.duration > 0.0f ? std::fmod(time_in, anim.duration) : time_in;
+    const std::vector<float>& in = ch.inputs;
+    const size_t count = in.size();
+    if (count == 0) continue;
+    size_t next = 0;
+    while (next < count && in[next] < time) next++;
+    if (next == 0) next = 1;
+    if (next >= count) next = 0;
+    const size_t prev = next == 0 ? count - 1 : next - 1;
+    const float t0 = in[prev], t1 = in[next];
+    const float dt = t1 < t0 ? anim.duration - t0 + t1 : t1 - t0;
+    const float current = t1 < t0 ? (time >= t0 ? time - t0 : (anim.duration - t0) + time) : time - t0;
+    float factor = 0.0f;
+    if (dt > 0.0001f) {
+      factor = current / dt;
+      factor = factor < 0.0f ? 0.0f : (factor > 1.0f ? 1.0f : factor);
+    }
+    const size_t stride = ch.interpolation == 2 ? 3 : 1, offset = ch.interpolation == 2 ? 1 : 0;  // CUBICSPLINE: the value of (in, value, out)
+    const size_t i0 = prev * stride + offset, i1 = next * stride + offset;
+    const float tf = ch.interpolation == 1 ? 0.0f : factor;  // STEP holds the previous key
+    GNode& node = w.gltf.nodes[ch.target_node];
+    const size_t comps = ch.kind == 1 ? 4 : 3, n_keys = ch.out.size() / comps;
+    if (i0 >= n_keys || i1 >= n_keys) continue;
+    const float* a = &ch.out[i0 * comps];
+    const float* b = &ch.out[i1 * comps];
+    if (ch.kind == 0) {
+      node.translation = v3_lerp(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]), tf);
+    } else if (ch.kind == 1) {
+      node.rotation = q_slerp(q_normalize(Quat{a[0], a[1], a[2], a[3]}), q_normalize(Quat{b[0], b[1], b[2], b[3]}), tf);
+    } else {
+      node.scale = v3_lerp(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]), tf);
+    }
+  }
+}
+
+// lib.rs:372-381 update_node_global (iterative: assets may nest deeper than the C stack should)
+static void update_globals(const ms_world& w, std::vector<M4>& globals) {
+  const size_t n = w.gltf.nodes.size();
+  globals.assign(n, m4_identity());
+  std::vector<std::pair<size_t, M4>> stack;
+  std::vector<uint8_t> seen(n, 0);
+  for (size_t root = 0; root < n; root++) {
+    if (w.gltf.nodes[root].parent >= 0) continue;
+    stack.emplace_back(root, m4_identity());
+    while (!stack.empty()) {
+      const size_t i = stack.back().first;
+      const M4 parent = stack.back().second;
+      stack.pop_back();
+      if (i >= n || seen[i]) continue;  // a malformed graph (cycle / shared child) is walked once
+      seen[i] = 1;
+      const GNode& node = w.gltf.nodes[i];
+      const M4 global = m4_mul(parent, m4_from_srt(node.scale, node.rotation, node.translation));
+      globals[i] = global;
+      for (size_t k = node.children.size(); k-- > 0;) stack.emplace_back(node.children[k], global);
+    }
+  }
+}
+
+static void world_update(ms_world& w, float time = 0.0f) {
+  // --- lib.rs:149-184: animation, then global transforms of the scene graph ---
+  if (!w.gltf.animations.empty()) {
+    const size_t ai = w.active_anim < w.gltf.animations.size() ? w.active_anim : 0;
+    const float duration = w.gltf.animations[ai].duration;
+    apply_animation(w, ai, duration > 0.001f ? std::fmod(time, duration) : 0.0f);
+  }
+  std::vector<M4> globals;
+  update_globals(w, globals);
+
   // --- rebuilder.rs:9-190: per geometry, vertices + BLAS + topology ---
   w.vertices.clear();
   w.normals.clear();
@@ -1056,9 +1154,32 @@ static void world_update(ms_world& w) {
     }
     std::vector<float> v4, n4, uv2;
     v4.reserve(geo.positions.size() * 4);
+    // rebuilder.rs:36-91: linear blend skinning with joint matrices global(joint) * inverse_bind
+    const GSkin* skin = (geo.skin_index >= 0 && (size_t)geo.skin_index < w.gltf.skins.size()) ? &w.gltf.skins[(size_t)geo.skin_index] : nullptr;
+    std::vector<M4> joint_mats;
+    if (skin)
+      for (size_t k = 0; k < skin->joints.size() && k < skin->inverse_bind.size(); k++)
+        joint_mats.push_back(m4_mul(skin->joints[k] < globals.size() ? globals[skin->joints[k]] : m4_identity(), skin->inverse_bind[k]));
     for (size_t i = 0; i < geo.positions.size(); i++) {
       V3 p = geo.positions[i], n = geo.normals[i];
       V2 uv = i < geo.uvs.size() ? geo.uvs[i] : V2{0, 0};
+      if (skin) {
+        M4 mat;
+        std::memset(mat.c, 0, sizeof(mat.c));
+        for (int k = 0; k < 4; k++) {
+          const float wk = geo.weights[i * 4 + (size_t)k];
+          const uint32_t jk = geo.joints[i * 4 + (size_t)k];
+          if (wk > 0.0f && jk < joint_mats.size())  // an out-of-range joint panics in the reference; skipped here
+            for (int c = 0; c < 4; c++)
+              for (int r = 0; r < 4; r++) mat.c[c][r] = mat.c[c][r] + joint_mats[jk].c[c][r] * wk;
+        }
+        bool any = false;
+        for (int c = 0; c < 4; c++)
+          for (int r = 0; r < 4; r++) any = any || mat.c[c][r] != 0.0f;
+        if (!any) mat = m4_identity();  // "if mat == Mat4::ZERO"
+        p = m4_transform_point3(mat, p);
+        n = normalize_or_zero(m4_transform_vector3(mat, n));
+      }
       if (is_nan(p)) p = v3(0, 0, 0);
       if (is_nan(n)) n = v3(0, 0, 1);
       const float pv[4] = {p.x, p.y, p.z, 1.0f}, nv[4] = {n.x, n.y, n.z, 0.0f};
@@ -1153,6 +1274,11 @@ extern "C" {
 const char* ms_last_error(void) { return g_last_error.c_str(); }
 
 ms_world* ms_world_create(const char* scene_name, const char* obj_source) {
+  return ms_world_create_glb(scene_name, obj_source, nullptr, 0);
+}
+
+ms_world* ms_world_create_glb(const char* scene_name, const char* obj_source, const uint8_t* glb, size_t glb_size) {
+  const bool has_glb = glb != nullptr;
   std::string name = scene_name ? scene_name : "cornell";
   ObjMesh mesh;
   bool has_mesh = obj_source != nullptr;
@@ -1169,7 +1295,7 @@ ms_world* ms_world_create(const char* scene_name, const char* obj_source) {
   } else if (name == "mesh") {
     w->scene = scene_mesh();
   } else if (name == "viewer") {
-    w->scene = scene_viewer(has_mesh ? &mesh : nullptr);
+    w->scene = scene_viewer(has_mesh ? &mesh : nullptr, has_glb);
   } else if (name == "instanced1000") {
     w->scene = scene_instanced1000();
   } else if (name == "sponza_like") {
@@ -1178,6 +1304,14 @@ ms_world* ms_world_create(const char* scene_name, const char* obj_source) {
     w->scene = scene_glass_blob();
   } else {
     w->scene = scene_cornell();
+  }
+  g_last_error.clear();
+  if (has_glb) {
+    // lib.rs:57-67: `let _ = loader::load_gltf(..)` — a GLB that fails to load leaves the procedural scene as it is;
+    // the reason is kept for ms_last_error()
+    std::string err;
+    if (!load_gltf(w->scene, w->gltf, glb, glb_size, err)) g_last_error = err;
+    w->scene.textures = w->gltf.textures;
   }
   for (const SceneInstance& si : w->scene.instances) {
     RawInstance ri;
@@ -1201,8 +1335,37 @@ ms_world* ms_world_create(const char* scene_name, const char* obj_source) {
 
 void ms_world_destroy(ms_world* w) { delete w; }
 
-void ms_world_update(ms_world* w, float /*time*/) {
-  if (w) world_update(*w);
+void ms_world_update(ms_world* w, float time) {
+  if (w) world_update(*w, time);
+}
+
+size_t ms_world_animation_count(const ms_world* w) { return w ? w->gltf.animations.size() : 0; }
+const char* ms_world_animation_name(const ms_world* w, size_t index) {
+  return (w && index < w->gltf.animations.size()) ? w->gltf.animations[index].name.c_str() : "";
+}
+void ms_world_set_animation(ms_world* w, size_t index) {
+  if (w && index < w->gltf.animations.size()) w->active_anim = index;
+}
+int ms_world_load_animation_glb(ms_world* w, const uint8_t* glb, size_t glb_size) {
+  if (!w || !glb) return -1;
+  SceneData tmp_scene;
+  GltfScene tmp;
+  std::string err;
+  if (!load_gltf(tmp_scene, tmp, glb, glb_size, err)) {
+    g_last_error = err;
+    return -1;
+  }
+  const int added = (int)tmp.animations.size();
+  for (GAnimation& a : tmp.animations) w->gltf.animations.push_back(std::move(a));
+  return added;
+}
+size_t ms_world_node_count(const ms_world* w) { return w ? w->gltf.nodes.size() : 0; }
+size_t ms_world_encoded_texture_count(const ms_world* w) { return w ? w->scene.textures.size() : 0; }
+const uint8_t* ms_world_encoded_texture(const ms_world* w, size_t index, size_t* size) {
+  if (size) *size = 0;
+  if (!w || index >= w->scene.textures.size()) return nullptr;
+  if (size) *size = w->scene.textures[index].size();
+  return w->scene.textures[index].data();
 }
 
 void ms_world_update_camera(ms_world* w, float width, float height) {

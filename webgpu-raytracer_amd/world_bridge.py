@@ -39,6 +39,19 @@ def _load():
         f = getattr(lib, "ms_world_" + name)
         f.restype = _U32P
         f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.ms_world_create_glb.restype = ctypes.c_void_p
+    lib.ms_world_create_glb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    for name in ("animation_count", "node_count", "encoded_texture_count"):
+        f = getattr(lib, "ms_world_" + name)
+        f.restype = ctypes.c_size_t
+        f.argtypes = [ctypes.c_void_p]
+    lib.ms_world_animation_name.restype = ctypes.c_char_p
+    lib.ms_world_animation_name.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.ms_world_set_animation.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.ms_world_load_animation_glb.restype = ctypes.c_int
+    lib.ms_world_load_animation_glb.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.ms_world_encoded_texture.restype = ctypes.POINTER(ctypes.c_uint8)
+    lib.ms_world_encoded_texture.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.ms_world_texture_count.restype = ctypes.c_size_t
     lib.ms_world_texture_count.argtypes = [ctypes.c_void_p]
     lib.ms_world_texture_rgba.restype = ctypes.POINTER(ctypes.c_uint8)
@@ -69,13 +82,17 @@ class WorldBridge:
 
     # world-bridge.ts:109-130
     def loadScene(self, sceneName, objSource=None, glbData=None):
-        if glbData is not None:
-            raise NotImplementedError("glTF/GLB input is out of scope (SURVEY.md §2)")
         self.close()
         obj = objSource.encode() if isinstance(objSource, str) else objSource
-        w = self._lib.ms_world_create(sceneName.encode(), obj)
+        if glbData is not None:
+            glb = bytes(glbData)
+            w = self._lib.ms_world_create_glb(sceneName.encode(), obj, glb, len(glb))
+        else:
+            w = self._lib.ms_world_create(sceneName.encode(), obj)
         if not w:
             raise ValueError(self._lib.ms_last_error().decode())
+        # a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
+        self.loadWarning = self._lib.ms_last_error().decode() if glbData is not None else ""
         self._world = w
         self._tex_blobs = {}
         self._last_wh = (-1, -1)
@@ -130,15 +147,42 @@ class WorldBridge:
     def hasWorld(self):
         return self._world is not None and len(self._cache.get("vertices", ())) > 0
 
+    # world-bridge.ts:98-99, 161-170
+    def getAnimationList(self):
+        n = int(self._lib.ms_world_animation_count(self._world)) if self._world else 0
+        return [self._lib.ms_world_animation_name(self._world, i).decode() for i in range(n)]
+
+    def loadAnimation(self, data):
+        b = bytes(data)
+        return int(self._lib.ms_world_load_animation_glb(self._world, b, len(b)))
+
+    def setAnimation(self, index):
+        self._lib.ms_world_set_animation(self._world, int(index))
+
+    @property
+    def nodeCount(self):
+        return int(self._lib.ms_world_node_count(self._world)) if self._world else 0
+
     @property
     def textureCount(self):
-        return int(self._lib.ms_world_texture_count(self._world)) if self._world else 0
+        if not self._world:
+            return 0
+        n = int(self._lib.ms_world_encoded_texture_count(self._world))   # glTF input: encoded images
+        return n if n else int(self._lib.ms_world_texture_count(self._world))
 
     def getTexture(self, index):
         """Encoded image bytes of texture `index` (world-bridge.ts:101-106, `World::get_texture_ptr/_len`
         lib.rs:359-381).  The synthetic scenes only hold raw texels, so the blob is their PNG encoding (cached)."""
         if index in self._tex_blobs:
             return self._tex_blobs[index]
+        if self._world and int(self._lib.ms_world_encoded_texture_count(self._world)):
+            n = ctypes.c_size_t()
+            p = self._lib.ms_world_encoded_texture(self._world, index, ctypes.byref(n))
+            if not p or n.value == 0:
+                return None                    # external / missing image: the renderer writes the white fallback layer
+            blob = bytes(np.ctypeslib.as_array(p, shape=(n.value,)))
+            self._tex_blobs[index] = blob
+            return blob
         rgba = self.getTextureRGBA(index)
         if rgba is None:
             return None
