@@ -104,3 +104,31 @@ def test_javascript_textured_render_matches_the_oracle(W, oracle_lib, addon):
         cpu.present()
     assert hashlib.sha256(cpu.readAccum().tobytes()).hexdigest() == got["accum_sha256"]
     assert hashlib.sha256(cpu.captureFrame()["data"].tobytes()).hexdigest() == got["rgba_sha256"]
+
+
+@needs_node
+def test_javascript_bridge_loads_a_glb_like_the_python_bridge(W, addon, tmp_path):
+    """loadScene(name, undefined, glbData) + update(t) + animation API from JS give the arrays the Python bridge gives."""
+    import test_gltf
+    b, _ = test_gltf.build_skinned(W)
+    b.image_texture(W.textures.encode_png(np.full((4, 4, 4), 200, np.uint8)))
+    glb = b.glb()
+    path = tmp_path / "strip.glb"
+    path.write_bytes(glb)
+    js = ("const {WorldBridge}=require('%s/index.js');const c=require('crypto');const fs=require('fs');(async()=>{"
+          "const b=new WorldBridge();await b.loadScene('viewer',undefined,new Uint8Array(fs.readFileSync('%s')));"
+          "b.setAnimation(0);b.update(0.3);b.updateCamera(64,48);const o={anims:b.getAnimationList(),warn:b.loadWarning,tex:b.textureCount,"
+          "texlen:b.getTexture(0).length};"
+          "for(const k of ['vertices','normals','mesh_topology','tlas','blas','instances','lights'])"
+          "o[k]=c.createHash('sha256').update(Buffer.from(b[k].buffer)).digest('hex');"
+          "const bad=new WorldBridge();await bad.loadScene('viewer',undefined,new Uint8Array([1,2,3,4]));o.badwarn=bad.loadWarning;"
+          "console.log(JSON.stringify(o));})()" % (NODE_DIR, path))
+    out = subprocess.run([node, "-e", js], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=glb)
+    br.update(0.3)
+    assert got["anims"] == ["bend", "anim"] and got["warn"] == "" and got["badwarn"] != "" and got["tex"] == 1
+    assert got["texlen"] == len(br.getTexture(0))
+    for k in ("vertices", "normals", "mesh_topology", "tlas", "blas", "instances", "lights"):
+        assert hashlib.sha256(np.ascontiguousarray(getattr(br, k)).tobytes()).hexdigest() == got[k], k

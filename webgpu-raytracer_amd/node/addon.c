@@ -214,9 +214,12 @@ static napi_value rtGetCounters(napi_env env, napi_callback_info info) {
 }
 
 /* --------------------------------------------------------------------- world */
+/* (sceneName, objSource | null, glbData | null) — World::new, lib.rs:45-102 */
 static napi_value msCreate(napi_env env, napi_callback_info info) {
-  napi_value a[2];
-  if (!get_args(env, info, 2, a)) return NULL;
+  napi_value a[3];
+  void* glb = NULL;
+  size_t glb_size = 0;
+  if (!get_args(env, info, 3, a) || !get_bytes(env, a[2], &glb, &glb_size)) return NULL;
   char name[64];
   size_t len = 0;
   napi_get_value_string_utf8(env, a[0], name, sizeof(name), &len);
@@ -229,7 +232,7 @@ static napi_value msCreate(napi_env env, napi_callback_info info) {
     obj = (char*)malloc(olen + 1);
     napi_get_value_string_utf8(env, a[1], obj, olen + 1, &olen);
   }
-  ms_world* w = ms_world_create(name, obj);
+  ms_world* w = glb ? ms_world_create_glb(name, obj, (const uint8_t*)glb, glb_size) : ms_world_create(name, obj);
   free(obj);
   if (!w) {
     napi_throw_error(env, NULL, ms_last_error());
@@ -343,6 +346,58 @@ static napi_value mtDecode(napi_env env, napi_callback_info info) {
   NAPI_OK(env, napi_set_named_property(env, obj, "height", h));
   return obj;
 }
+/* animations: get_animation_count/name, set_animation, load_animation_glb (lib.rs:106-147) */
+static napi_value msAnimationNames(napi_env env, napi_callback_info info) {
+  napi_value a[1], arr;
+  if (!get_args(env, info, 1, a)) return NULL;
+  const ms_world* w = (const ms_world*)get_ptr(env, a[0]);
+  const size_t n = ms_world_animation_count(w);
+  NAPI_OK(env, napi_create_array_with_length(env, n, &arr));
+  for (size_t i = 0; i < n; i++) {
+    napi_value s;
+    NAPI_OK(env, napi_create_string_utf8(env, ms_world_animation_name(w, i), NAPI_AUTO_LENGTH, &s));
+    NAPI_OK(env, napi_set_element(env, arr, (uint32_t)i, s));
+  }
+  return arr;
+}
+static napi_value msSetAnimation(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  ms_world_set_animation((ms_world*)get_ptr(env, a[0]), get_u32(env, a[1]));
+  return NULL;
+}
+static napi_value msLoadAnimation(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  void* p = NULL;
+  size_t n = 0;
+  if (!get_args(env, info, 2, a) || !get_bytes(env, a[1], &p, &n)) return NULL;
+  return make_int(env, ms_world_load_animation_glb((ms_world*)get_ptr(env, a[0]), (const uint8_t*)p, n));
+}
+static napi_value msLastError(napi_env env, napi_callback_info info) {
+  napi_value s;
+  (void)info;
+  NAPI_OK(env, napi_create_string_utf8(env, ms_last_error(), NAPI_AUTO_LENGTH, &s));
+  return s;
+}
+static napi_value msEncodedTextureCount(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  return make_int(env, (int)ms_world_encoded_texture_count((const ms_world*)get_ptr(env, a[0])));
+}
+/* (world, index) -> Uint8Array of the encoded image, or undefined for an external / missing image */
+static napi_value msEncodedTexture(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  size_t n = 0;
+  const uint8_t* src = ms_world_encoded_texture((const ms_world*)get_ptr(env, a[0]), get_u32(env, a[1]), &n);
+  if (!src || n == 0) return NULL;
+  void* dst = NULL;
+  napi_value ab, ta;
+  NAPI_OK(env, napi_create_arraybuffer(env, n, &dst, &ab));
+  memcpy(dst, src, n);
+  NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta));
+  return ta;
+}
 static napi_value msTextureCount(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -375,7 +430,10 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"rtPresent", rtPresent}, {"rtSync", rtSync}, {"rtCapture", rtCapture}, {"rtReadAccum", rtReadAccum},
                {"rtGetCounters", rtGetCounters}, {"msCreate", msCreate}, {"msDestroy", msDestroy},
                {"msUpdate", msUpdate}, {"msUpdateCamera", msUpdateCamera}, {"msGet", msGet},
-               {"msTextureCount", msTextureCount}, {"msTexture", msTexture}};
+               {"msTextureCount", msTextureCount}, {"msTexture", msTexture},
+               {"msAnimationNames", msAnimationNames}, {"msSetAnimation", msSetAnimation},
+               {"msLoadAnimation", msLoadAnimation}, {"msLastError", msLastError},
+               {"msEncodedTextureCount", msEncodedTextureCount}, {"msEncodedTexture", msEncodedTexture}};
   for (size_t i = 0; i < sizeof(table) / sizeof(table[0]); i++) {
     napi_value fn;
     if (napi_create_function(env, table[i].name, NAPI_AUTO_LENGTH, table[i].fn, NULL, &fn) != napi_ok) return NULL;

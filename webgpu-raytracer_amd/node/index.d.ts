@@ -42,6 +42,11 @@ export class WorldBridge {
   readonly textureCount: number;
   readonly hasWorld: boolean;
   getTextureRGBA(index: number): Uint8Array | undefined;
-  /** encoded image bytes (PNG), as world-bridge.ts:101-106 hands them out */
+  getAnimationList(): string[];
+  loadAnimation(data: Uint8Array): number;
+  setAnimation(index: number): void;
+  /** why a GLB passed to loadScene was ignored ('' when it loaded) */
+  loadWarning: string;
+  /** encoded image bytes (PNG / JPEG), as world-bridge.ts:101-106 hands them out */
   getTexture(index: number): Uint8Array | undefined;
 }

@@ -130,10 +130,12 @@ class WebGPURenderer {
 class WorldBridge {
   constructor() { this._w = null; this._cache = {}; this.hasNewData = false; this.hasNewGeometry = false; this._wh = [-1, -1]; }
   async initWasm() {}
+  // world-bridge.ts:109-130; glbData: Uint8Array of a .glb (or .gltf JSON with data URIs)
   async loadScene(sceneName, objSource, glbData) {
-    if (glbData) throw new Error('glTF/GLB input is out of scope');
     if (this._w) native.msDestroy(this._w);
-    this._w = native.msCreate(sceneName, objSource === undefined ? null : objSource);
+    this._w = native.msCreate(sceneName, objSource === undefined ? null : objSource, glbData || null);
+    // a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
+    this.loadWarning = glbData ? native.msLastError() : '';
     this._wh = [-1, -1];
     this._refresh();
     this.hasNewData = true;
@@ -161,11 +163,19 @@ class WorldBridge {
   get lightCount() { return this._cache.lights.length / 2; }
   get draw_commands() { return this._cache.draw_commands; }
   get cameraData() { return this._cache.camera; }
-  get textureCount() { return this._w ? native.msTextureCount(this._w) : 0; }
+  get textureCount() {
+    if (!this._w) return 0;
+    return native.msEncodedTextureCount(this._w) || native.msTextureCount(this._w);
+  }
+  // world-bridge.ts:98-99, 161-170
+  getAnimationList() { return this._w ? native.msAnimationNames(this._w) : []; }
+  loadAnimation(data) { return native.msLoadAnimation(this._w, data); }
+  setAnimation(index) { native.msSetAnimation(this._w, index); }
   get hasWorld() { return !!this._w && this._cache.vertices.length > 0; }
   getTextureRGBA(i) { return native.msTexture(this._w, i); }
   // world-bridge.ts:101-106 hands out ENCODED images; the synthetic scenes hold raw texels, so encode them as PNG
   getTexture(i) {
+    if (native.msEncodedTextureCount(this._w)) return native.msEncodedTexture(this._w, i);   // glTF input
     const rgba = this.getTextureRGBA(i);
     return rgba ? encodePng(rgba, 1024, 1024) : undefined;
   }
