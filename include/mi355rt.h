@@ -33,7 +33,8 @@ enum {
   RT_ERR_INVALID = -1,
   RT_ERR_HIP = -2,
   RT_ERR_NOT_READY = -3,
-  RT_ERR_NO_DEVICE = -4
+  RT_ERR_NO_DEVICE = -4,
+  RT_ERR_INTERNAL = -5
 };
 
 /* updateBuffer(type, data) kinds — WebGPURenderer.ts:55-60 */
@@ -86,6 +87,18 @@ int rt_upload_textures(rt_ctx* ctx, const uint8_t* rgba, uint32_t layers);
 int rt_alloc_texture_layers(rt_ctx* ctx, uint32_t layers);
 int rt_upload_texture_image(rt_ctx* ctx, uint32_t layer, const uint8_t* rgba, uint32_t width, uint32_t height);
 int rt_read_texture_layer(rt_ctx* ctx, uint32_t layer, uint8_t* out_rgba, size_t cap);
+
+/* BLAS build for World::update(t) on the GPU: the binned-SAH builder of bvh/blas.rs
+ * (BVHBuilder::build_with_ids, called per geometry per frame at rebuilder.rs:93-98) — same tree, same triangle order
+ * as the scene compiler's CPU restatement, byte for byte.
+ *   verts4      4 f32 per vertex (the skinned positions rebuilder.rs hands to the builder), n_verts of them
+ *   indices     3 u32 per triangle
+ *   nodes_out   8 f32 per node: {min.xyz, bits(skip)} {max.xyz, bits(data)}, BLAS-local skip pointers, leaf data =
+ *               (first << 3) | count with `first` an index into order_out; room for nodes_cap nodes (2 * n_tris is enough)
+ *   order_out   n_tris u32: position in the BLAS's triangle order -> original triangle id
+ * The signature (ctx first) is the one ms_world_set_blas_builder (mi355scene.h) takes as its hook. */
+int rt_build_blas(rt_ctx* ctx, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
+                  float* nodes_out, uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
 
 /* updateBuffer(type, data) -> needsRebind — WebGPURenderer.ts:55-60, ResourceManager.ts:230-284 */
 int rt_upload(rt_ctx* ctx, rt_kind kind, const void* data, size_t bytes);

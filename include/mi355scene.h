@@ -56,6 +56,15 @@ const char* ms_world_animation_name(const ms_world* w, size_t index);
 void ms_world_set_animation(ms_world* w, size_t index);
 int ms_world_load_animation_glb(ms_world* w, const uint8_t* glb, size_t glb_size);
 size_t ms_world_node_count(const ms_world* w);
+
+/* Replace the BLAS builder World::update runs per geometry (BVHBuilder::build_with_ids, rebuilder.rs:93-98) with one
+ * that returns the SAME nodes and triangle order — libmi355rt.so's rt_build_blas has this signature with its rt_ctx*
+ * as `user` (the per-frame rebuild of an animated scene moves to the GPU).  fn == NULL restores the
+ * CPU builder.  When the hook fails (< 0) the CPU builder does that geometry and ms_last_error() reports it after
+ * ms_world_update. */
+typedef int (*ms_blas_builder)(void* user, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
+                               float* nodes_out, uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
+void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user);
 /* World::update_camera(width, height) lib.rs:347-352. */
 void ms_world_update_camera(ms_world* w, float width, float height);
 

@@ -299,3 +299,100 @@ def test_animated_textured_glb_renders_like_the_oracle(W, oracle_lib):
         images.append(gpu.readAccum().copy())
         gpu.destroy()
     assert not np.array_equal(images[0], images[1])          # the pose changed the picture
+
+
+def big_skinned_glb(W, nu=192, nv=96):
+    """a skinned tube: nu x nv quads, two joints, one rotation channel"""
+    b = G.GltfBuilder()
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False, dtype=f32)
+    v = np.linspace(0, 1, nv + 1, dtype=f32)
+    uu, vv = np.meshgrid(u, v)
+    pos = np.stack([0.15 * np.cos(uu), vv, 0.15 * np.sin(uu)], -1).reshape(-1, 3).astype(f32)
+    nrm = np.stack([np.cos(uu), np.zeros_like(uu), np.sin(uu)], -1).reshape(-1, 3).astype(f32)
+    idx = []
+    for j in range(nv):
+        for i in range(nu):
+            a, bq = j * nu + i, j * nu + (i + 1) % nu
+            idx += [a, bq, bq + nu, a, bq + nu, a + nu]
+    w1 = np.clip((pos[:, 1] - 0.3) * 2.5, 0, 1).astype(f32)
+    weights = np.stack([1 - w1, w1, 0 * w1, 0 * w1], 1).astype(f32)
+    joints = np.tile(np.array([0, 1, 0, 0], np.uint16), (len(pos), 1))
+    acc = dict(POSITION=b.accessor(pos, G.F32, "VEC3", minmax=True), NORMAL=b.accessor(nrm, G.F32, "VEC3"),
+               JOINTS_0=b.accessor(joints, G.U16, "VEC4"), WEIGHTS_0=b.accessor(weights, G.F32, "VEC4"))
+    b.doc["meshes"] = [{"primitives": [{"attributes": acc, "indices": b.accessor(np.array(idx, np.uint32), G.U32, "SCALAR")}]}]
+    ibm = np.stack([np.eye(4, dtype=f32), np.eye(4, dtype=f32)])
+    ibm[1][1, 3] = -0.5
+    b.doc["nodes"] = [{"mesh": 0, "skin": 0}, {"children": [2]}, {"translation": [0, 0.5, 0]}]
+    b.doc["skins"] = [{"joints": [1, 2], "inverseBindMatrices": b.accessor(np.stack([m.T for m in ibm]), G.F32, "MAT4")}]
+    s45, c45 = np.sin(np.pi / 8), np.cos(np.pi / 8)
+    b.doc["animations"] = [{"name": "sway", "samplers": [{"input": b.accessor(np.array([0, 1, 2], f32), G.F32, "SCALAR", minmax=True),
+                                                          "output": b.accessor(np.array([[0, 0, -s45, c45], [0, 0, s45, c45], [0, 0, -s45, c45]], f32), G.F32, "VEC4")}],
+                            "channels": [{"sampler": 0, "target": {"node": 2, "path": "rotation"}}]}]
+    return b.glb(), len(idx) // 3
+
+
+BRIDGE_ARRAYS = ("vertices", "normals", "uvs", "mesh_topology", "tlas", "blas", "instances", "lights", "draw_commands")
+
+
+@pytest.mark.gpu
+def test_gpu_blas_builder_equals_the_cpu_builder(W):
+    """rt_build_blas against the scene compiler's BlasBuilder: node array and triangle order byte for byte, on meshes from a
+    single triangle to 263 k triangles, degenerate and flat ones included; then as the hook of update(t)."""
+    r = W.WebGPURenderer(0)
+    rng = np.random.default_rng(2)
+
+    def cpu_blas(verts4, idx):
+        # the CPU builder through the bridge: a one-geometry GLB (static mesh) — geometry 2 of the viewer scene
+        b = G.GltfBuilder()
+        b.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": b.accessor(verts4[:, :3], G.F32, "VEC3", minmax=True)},
+                                            "indices": b.accessor(idx, G.U32, "SCALAR")}]}]
+        b.doc["nodes"] = [{"mesh": 0}]
+        br = W.WorldBridge()
+        br.loadScene("viewer", glbData=b.glb())
+        blas = np.asarray(br.blas).reshape(-1, 8)
+        inst = np.asarray(br.instances).reshape(-1, 36)
+        off = int([row for row in inst if row[34:35].view(np.uint32)[0] == 2][0][32:33].view(np.uint32)[0])
+        nodes = blas[off:].copy()
+        topo = np.asarray(br.mesh_topology).reshape(-1, 20)
+        return nodes, topo[topo[:, 3] == 2][:, :3] - ENV_VERTS, 12      # 12 = triangles of the room before this geometry
+
+    cases = []
+    for n_tris in (1, 3, 4, 5, 9, 64, 1000, 20000):
+        verts = rng.random((n_tris * 3, 3), dtype=f32) * f32(2) - f32(1)
+        if n_tris == 64:
+            verts[:, 2] = 0.25                      # flat: padded boxes
+        if n_tris == 9:
+            verts[:] = verts[0]                     # all triangles identical: no split possible -> fat leaf (count > 7 quirk)
+        cases.append((np.concatenate([verts, np.ones((len(verts), 1), f32)], 1), np.arange(n_tris * 3, dtype=np.uint32)))
+    grid = np.stack(np.meshgrid(np.linspace(-1, 1, 40, dtype=f32), np.linspace(-1, 1, 40, dtype=f32)), -1).reshape(-1, 2)
+    gv = np.concatenate([grid, np.zeros((len(grid), 1), f32), np.ones((len(grid), 1), f32)], 1)       # z = +0 / -0 mix
+    gv[::3, 2] = -0.0
+    gi = []
+    for j in range(39):
+        for i in range(39):
+            a = j * 40 + i
+            gi += [a, a + 1, a + 41, a, a + 41, a + 40]
+    cases.append((gv, np.array(gi, np.uint32)))
+    for verts4, idx in cases:
+        nodes, order = r.buildBlas(verts4, idx)
+        want_nodes, want_tris, topo0 = cpu_blas(verts4, idx)
+        # the bridge stores leaf `first` as a global topology index: undo that for the comparison
+        wn = want_nodes.copy()
+        data = wn[:, 7].view(np.uint32)
+        leaf = data != 0
+        data[leaf] = (((data[leaf] >> 3) - topo0) << 3) | (data[leaf] & 7)
+        assert nodes.shape == wn.shape, (len(idx) // 3, nodes.shape, wn.shape)
+        assert np.array_equal(nodes.view(np.uint32), wn.view(np.uint32)), len(idx) // 3
+        assert np.array_equal(idx.reshape(-1, 3)[order], want_tris)
+    # as the hook of update(t): every bridge array identical, on the big static scene and on an animated one
+    for scene, glb in (("sponza_like", None), ("glass_blob", None), ("viewer", big_skinned_glb(W)[0])):
+        cpu_b, gpu_b = W.WorldBridge(), W.WorldBridge()
+        gpu_b.setBlasBuilder(r)
+        cpu_b.loadScene(scene, glbData=glb)
+        gpu_b.loadScene(scene, glbData=glb)
+        for t in ((0.0,) if glb is None else (0.0, 0.4, 1.7)):
+            cpu_b.update(t)
+            gpu_b.update(t)
+            for k in BRIDGE_ARRAYS:
+                assert np.array_equal(np.asarray(getattr(cpu_b, k)).view(np.uint32), np.asarray(getattr(gpu_b, k)).view(np.uint32)), (scene, t, k)
+    r.destroy()

@@ -1,0 +1,328 @@
+// bvh_build.hip.h — binned-SAH BLAS build on the GPU, bit-identical to the scene compiler's CPU builder.
+//
+// SURVEY.md §8f N1 (GPU half).  The reference rebuilds every BLAS on one CPU thread inside World::update(t)
+// (rust-shader-tools/src/lib.rs:186-193 -> rebuilder.rs:93-98 -> bvh/blas.rs), 147 ms for 263 k triangles here — 26x the
+// time this renderer needs to trace a frame of that scene, so an animated scene is build-bound.  A different builder
+// (LBVH, refit) would change the traversal order and with it tie-breaks and the node / triangle counters, so this one
+// makes the SAME tree: 16 bins on the longest axis of the node's box, SAH sweep, two-pointer partition, costlier child
+// first, leaves at <= 4 triangles (blas.rs:99-234 as restated in csrc/scene/scene_compiler.cpp BlasBuilder; the
+// parity test compares node arrays and triangle order byte for byte).
+//
+// Shape: breadth-first, one launch per tree level, one 256-thread workgroup per active node.  Per node:
+//   1. box of the range (block reduction over order-mapped triangle boxes)
+//   2. leaf test / axis / bin scale (one lane), 16 bins of {count, box} in LDS (LDS atomics on order-preserving keys)
+//   3. SAH sweep and split choice (one lane; 15 candidates)
+//   4. the two-pointer partition of blas.rs:179-199 without its sequential loop: the k-th misplaced element from the left
+//      is exchanged with the k-th misplaced element from the right, which is exactly what the pointer walk does;
+//      ranks come from block prefix sums over the two regions, then the swaps run in parallel
+//   5. children's ranges written to the other order buffer, rotated when the right child is the costlier one
+// Node ids are handed out breadth-first (atomic counter); the stackless pre-order layout the traversal needs is made at
+// the end: subtree sizes bottom-up, pre-order indices top-down (one tiny launch per level each), then one emit pass.
+// f32 min/max run on order-preserving u32 keys, i.e. -0 < +0: the sign of a zero bound is the one thing a sequential
+// f32::min chain leaves to the visiting order (Rust documents it as unspecified); the CPU builder uses the same rule.
+#ifndef MI355RT_BVH_BUILD_HIP_H
+#define MI355RT_BVH_BUILD_HIP_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bvhb {
+
+constexpr int kThreads = 256;
+constexpr int kBins = 16;
+
+struct BNode {  // breadth-first build record
+  float mn[3];
+  uint32_t first;
+  float mx[3];
+  uint32_t count;
+  int32_t left, right;  // BFS ids, -1 for a leaf
+  uint32_t size, dfs;   // subtree size (nodes), pre-order index
+};
+
+struct Build {
+  const float4* tri_mn;  // per triangle: padded box and centre (blas.rs:63-90)
+  const float4* tri_mx;
+  const float4* tri_c;
+  uint32_t* order_in;    // position -> triangle id at this level (swapped in place, then copied out)
+  uint32_t* order_out;
+  uint32_t* order_final; // leaves park their range here
+  uint32_t* scratch_l;   // positions of misplaced elements, by rank
+  uint32_t* scratch_r;
+  BNode* nodes;
+  uint32_t* counters;    // [0] next node id, [1] nodes appended to the next level
+};
+
+__device__ __forceinline__ uint32_t key_of(float f) {  // order-preserving: a < b  <=>  key(a) < key(b); -0 < +0
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_of(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float tmin(float a, float b) { return key_of(b) < key_of(a) ? b : a; }
+__device__ __forceinline__ float tmax(float a, float b) { return key_of(b) > key_of(a) ? b : a; }
+
+// blas.rs:63-90: triangle box, padded by 1e-5 on a flat axis, and its centre
+__global__ __launch_bounds__(256) void k_tri_boxes(const float4* __restrict__ pos, const uint32_t* __restrict__ idx, uint32_t n_tris,
+                                                    float4* __restrict__ tri_mn, float4* __restrict__ tri_mx,
+                                                    float4* __restrict__ tri_c, uint32_t* __restrict__ order) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= n_tris) return;
+  const float4 a = pos[idx[3 * t]], b = pos[idx[3 * t + 1]], c = pos[idx[3 * t + 2]];
+  float mn[3] = {tmin(tmin(a.x, b.x), c.x), tmin(tmin(a.y, b.y), c.y), tmin(tmin(a.z, b.z), c.z)};
+  float mx[3] = {tmax(tmax(a.x, b.x), c.x), tmax(tmax(a.y, b.y), c.y), tmax(tmax(a.z, b.z), c.z)};
+  float ce[3];
+  for (int k = 0; k < 3; k++) {
+    const float size = mx[k] - mn[k];
+    const float pad = size < 1e-5f ? 1e-5f : 0.0f;
+    mn[k] = mn[k] - pad * 0.5f;
+    mx[k] = mx[k] + pad * 0.5f;
+    ce[k] = (mn[k] + mx[k]) * 0.5f;
+  }
+  tri_mn[t] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+  tri_mx[t] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+  tri_c[t] = make_float4(ce[0], ce[1], ce[2], 0.0f);
+  order[t] = t;
+}
+
+__device__ __forceinline__ uint32_t bin_of(float val, float split_min, float scale) {  // `as usize` then min(BINS - 1)
+  const float f = (val - split_min) * scale;
+  if (!(f > 0.0f)) return 0u;  // NaN or <= 0
+  if (f >= (float)(kBins - 1)) return (uint32_t)(kBins - 1);
+  return (uint32_t)f;
+}
+__device__ __forceinline__ float axis_of(const float4& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+__device__ __forceinline__ float area_of(const float mn[3], const float mx[3]) {  // primitives.rs AABB::area
+  const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+  if (dx < 0.0f || dy < 0.0f || dz < 0.0f) return 0.0f;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+// exclusive prefix sum of a flag over the 256 threads of the block; returns this thread's rank and the block total
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_wave, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  const uint32_t in_wave = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  __syncthreads();  // s_wave may still be read by the previous call
+  if (lane == 0u) s_wave[wave] = (uint32_t)__builtin_popcountll(m);
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+  total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  return before + in_wave;
+}
+
+__global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restrict__ active_in, uint32_t n_active,
+                                                uint32_t* __restrict__ active_out) {
+  __shared__ uint32_t s_red[4][6];
+  __shared__ uint32_t s_bin_cnt[kBins];
+  __shared__ uint32_t s_bin_box[kBins][6];
+  __shared__ uint32_t s_wave[4];
+  __shared__ float s_f[2];        // split_min, scale
+  __shared__ int32_t s_i[6];      // leaf flag, axis, best split, L, rotate, nbad
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= n_active) return;
+  const uint32_t id = active_in[blockIdx.x];
+  const uint32_t first = B.nodes[id].first, count = B.nodes[id].count, end = first + count;
+
+  // ---- 1. box of the range
+  uint32_t k[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  for (uint32_t p = first + tid; p < end; p += kThreads) {
+    const uint32_t t = B.order_in[p];
+    const float4 a = B.tri_mn[t], b = B.tri_mx[t];
+    k[0] = min(k[0], key_of(a.x)); k[1] = min(k[1], key_of(a.y)); k[2] = min(k[2], key_of(a.z));
+    k[3] = max(k[3], key_of(b.x)); k[4] = max(k[4], key_of(b.y)); k[5] = max(k[5], key_of(b.z));
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int c = 0; c < 6; c++) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)k[c], off, 64);
+      k[c] = c < 3 ? min(k[c], o) : max(k[c], o);
+    }
+  if (lane == 0u)
+    for (int c = 0; c < 6; c++) s_red[wave][c] = k[c];
+  __syncthreads();
+  if (tid == 0u) {
+    float mn[3], mx[3];
+    for (int c = 0; c < 3; c++) {
+      mn[c] = float_of(min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c])));
+      mx[c] = float_of(max(max(s_red[0][c + 3], s_red[1][c + 3]), max(s_red[2][c + 3], s_red[3][c + 3])));
+      B.nodes[id].mn[c] = mn[c];
+      B.nodes[id].mx[c] = mx[c];
+    }
+    int leaf = count <= 4u;
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    const int axis = ey > ex ? 1 : ((ez > ex && ez > ey) ? 2 : 0);   // blas.rs:127-133
+    const float split_len = axis == 0 ? ex : (axis == 1 ? ey : ez);
+    if (split_len < 1e-6f) leaf = 1;
+    s_i[0] = leaf;
+    s_i[1] = axis;
+    s_f[0] = mn[axis];
+    s_f[1] = (float)kBins / split_len;
+  }
+  if (tid < (uint32_t)kBins) {
+    s_bin_cnt[tid] = 0u;
+    for (int c = 0; c < 3; c++) {
+      s_bin_box[tid][c] = 0xffffffffu;   // above every key: an empty bin is (+inf, -inf) after decoding
+      s_bin_box[tid][c + 3] = 0u;
+    }
+  }
+  __syncthreads();
+  const int axis = s_i[1];
+  const float split_min = s_f[0], scale = s_f[1];
+  if (!s_i[0]) {
+    // ---- 2. bins
+    for (uint32_t p = first + tid; p < end; p += kThreads) {
+      const uint32_t t = B.order_in[p];
+      const uint32_t b = bin_of(axis_of(B.tri_c[t], axis), split_min, scale);
+      const float4 a = B.tri_mn[t], c = B.tri_mx[t];
+      atomicAdd(&s_bin_cnt[b], 1u);
+      atomicMin(&s_bin_box[b][0], key_of(a.x)); atomicMin(&s_bin_box[b][1], key_of(a.y)); atomicMin(&s_bin_box[b][2], key_of(a.z));
+      atomicMax(&s_bin_box[b][3], key_of(c.x)); atomicMax(&s_bin_box[b][4], key_of(c.y)); atomicMax(&s_bin_box[b][5], key_of(c.z));
+    }
+    __syncthreads();
+    // ---- 3. SAH sweep (blas.rs:149-177)
+    if (tid == 0u) {
+      float l_area[kBins], r_area[kBins];
+      uint32_t l_cnt[kBins], r_cnt[kBins];
+      const float inf = __uint_as_float(0x7f800000u);
+      float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+      uint32_t sum = 0;
+      for (int i = 0; i < kBins; i++) {
+        sum += s_bin_cnt[i];
+        for (int c = 0; c < 3; c++) {
+          // an untouched bin decodes to NaN-free sentinels only through the keys: compare keys, not floats
+          const float bmn = s_bin_cnt[i] ? float_of(s_bin_box[i][c]) : inf, bmx = s_bin_cnt[i] ? float_of(s_bin_box[i][c + 3]) : -inf;
+          cmn[c] = tmin(cmn[c], bmn);
+          cmx[c] = tmax(cmx[c], bmx);
+        }
+        l_area[i] = area_of(cmn, cmx);
+        l_cnt[i] = sum;
+      }
+      for (int c = 0; c < 3; c++) { cmn[c] = inf; cmx[c] = -inf; }
+      sum = 0;
+      for (int i = kBins - 1; i >= 0; i--) {
+        sum += s_bin_cnt[i];
+        for (int c = 0; c < 3; c++) {
+          const float bmn = s_bin_cnt[i] ? float_of(s_bin_box[i][c]) : inf, bmx = s_bin_cnt[i] ? float_of(s_bin_box[i][c + 3]) : -inf;
+          cmn[c] = tmin(cmn[c], bmn);
+          cmx[c] = tmax(cmx[c], bmx);
+        }
+        r_area[i] = area_of(cmn, cmx);
+        r_cnt[i] = sum;
+      }
+      float best = inf;
+      int best_split = -1;
+      for (int i = 0; i < kBins - 1; i++) {
+        if (l_cnt[i] == 0u || r_cnt[i + 1] == 0u) continue;
+        const float cost = l_area[i] * (float)l_cnt[i] + r_area[i + 1] * (float)r_cnt[i + 1];
+        if (cost < best) {
+          best = cost;
+          best_split = i;
+        }
+      }
+      int leaf = best_split < 0;
+      uint32_t L = 0;
+      int rotate = 0;
+      if (!leaf) {
+        L = l_cnt[best_split];
+        if (L == 0u || L == count) leaf = 1;
+        const float l_cost = l_area[best_split] * (float)L, r_cost = r_area[best_split + 1] * (float)(count - L);
+        rotate = r_cost > l_cost;   // blas.rs:209-217: the costlier child goes first
+      }
+      s_i[0] = leaf;
+      s_i[2] = best_split;
+      s_i[3] = (int32_t)L;
+      s_i[4] = rotate;
+    }
+    __syncthreads();
+  }
+  if (s_i[0]) {  // leaf: blas.rs:111-115 (a count above 7 overflows the 3-bit field exactly like the reference)
+    for (uint32_t p = first + tid; p < end; p += kThreads) B.order_final[p] = B.order_in[p];
+    if (tid == 0u) {
+      B.nodes[id].left = -1;
+      B.nodes[id].right = -1;
+    }
+    return;
+  }
+  const uint32_t split = (uint32_t)s_i[2], L = (uint32_t)s_i[3];
+  const bool rotate = s_i[4] != 0;
+  // ---- 4. partition: rank the misplaced elements of both regions
+  uint32_t run_l = 0, run_r = 0;
+  for (uint32_t base = 0; base < L; base += kThreads) {
+    const uint32_t p = first + base + tid;
+    bool bad = false;
+    if (base + tid < L) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) > split;
+    uint32_t total;
+    const uint32_t r = block_rank(bad, s_wave, total);
+    if (bad) B.scratch_l[first + run_l + r] = p;
+    run_l += total;
+  }
+  const uint32_t R = count - L;
+  for (uint32_t base = 0; base < R; base += kThreads) {
+    const uint32_t p = end - 1u - (base + tid);  // from the right end
+    bool bad = false;
+    if (base + tid < R) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) <= split;
+    uint32_t total;
+    const uint32_t r = block_rank(bad, s_wave, total);
+    if (bad) B.scratch_r[first + run_r + r] = p;
+    run_r += total;
+  }
+  __syncthreads();  // scratch writes of this block are visible to this block
+  for (uint32_t q = tid; q < run_l; q += kThreads) {
+    const uint32_t a = B.scratch_l[first + q], b = B.scratch_r[first + q];
+    const uint32_t ta = B.order_in[a], tb = B.order_in[b];
+    B.order_in[a] = tb;
+    B.order_in[b] = ta;
+  }
+  __syncthreads();
+  // ---- 5. children
+  for (uint32_t p = first + tid; p < end; p += kThreads) {
+    const uint32_t rel = p - first;
+    const uint32_t nrel = rotate ? (rel >= L ? rel - L : rel + R) : rel;
+    B.order_out[first + nrel] = B.order_in[p];
+  }
+  if (tid == 0u) {
+    const uint32_t l_count = rotate ? R : L;
+    const uint32_t ids = atomicAdd(&B.counters[0], 2u);
+    B.nodes[ids].first = first;
+    B.nodes[ids].count = l_count;
+    B.nodes[ids + 1u].first = first + l_count;
+    B.nodes[ids + 1u].count = count - l_count;
+    B.nodes[id].left = (int32_t)ids;
+    B.nodes[id].right = (int32_t)(ids + 1u);
+    const uint32_t slot = atomicAdd(&B.counters[1], 2u);
+    active_out[slot] = ids;
+    active_out[slot + 1u] = ids + 1u;
+  }
+}
+
+// subtree sizes, one level at a time from the deepest to the root
+__global__ __launch_bounds__(256) void k_sizes(BNode* nodes, uint32_t id0, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  BNode& nd = nodes[id0 + i];
+  nd.size = nd.left < 0 ? 1u : 1u + nodes[nd.left].size + nodes[nd.right].size;
+}
+// pre-order indices, one level at a time from the root down (the root's is 0)
+__global__ __launch_bounds__(256) void k_preorder(BNode* nodes, uint32_t id0, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const BNode& nd = nodes[id0 + i];
+  if (nd.left < 0) return;
+  nodes[nd.left].dfs = nd.dfs + 1u;
+  nodes[nd.right].dfs = nd.dfs + 1u + nodes[nd.left].size;
+}
+// the node array the traversal reads: {min, skip} {max, data}, skip = index after the subtree (BLAS-local)
+__global__ __launch_bounds__(256) void k_emit(const BNode* __restrict__ nodes, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const BNode nd = nodes[i];
+  const uint32_t skip = nd.dfs + nd.size;
+  const uint32_t data = nd.left < 0 ? ((nd.first << 3) | nd.count) : 0u;
+  out[2 * nd.dfs] = make_float4(nd.mn[0], nd.mn[1], nd.mn[2], __uint_as_float(skip));
+  out[2 * nd.dfs + 1] = make_float4(nd.mx[0], nd.mx[1], nd.mx[2], __uint_as_float(data));
+}
+
+}  // namespace bvhb
+#endif

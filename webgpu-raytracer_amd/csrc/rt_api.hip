@@ -19,6 +19,7 @@
 
 #include "../../include/mi355rt.h"
 #include "kernels.hip.h"
+#include "bvh_build.hip.h"
 
 namespace {
 
@@ -44,6 +45,8 @@ struct rt_ctx {
 
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
+  uint32_t bv_levels = 0;
+  DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters;  // rt_build_blas work space
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
@@ -319,7 +322,8 @@ void rt_destroy(rt_ctx* c) {
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
-                         &c->tex_staging};
+                         &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
+                         &c->bv_counters};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -442,6 +446,89 @@ int rt_read_texture_layer(rt_ctx* c, uint32_t layer, uint8_t* out, size_t cap) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(out, (const uint8_t*)c->textures.ptr + (size_t)layer * bytes, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+// Binned-SAH BLAS build on the GPU (csrc/bvh_build.hip.h): the tree and the triangle order of the scene compiler's
+// BlasBuilder, byte for byte.  Host arrays in, host arrays out (the scene compiler consumes them).
+int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
+                  uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out) {
+  if (!c || !n_nodes_out) return RT_ERR_INVALID;
+  *n_nodes_out = 0;
+  if (n_tris == 0) return RT_OK;
+  if (!verts4 || !indices || !nodes_out || !order_out || n_verts == 0) return fail(c, RT_ERR_INVALID, "rt_build_blas: null argument");
+  if (n_tris > (1u << 28)) return fail(c, RT_ERR_INVALID, "rt_build_blas: too many triangles for the 29-bit leaf field");
+  for (size_t i = 0; i < (size_t)n_tris * 3; i++)
+    if (indices[i] >= n_verts) return fail(c, RT_ERR_INVALID, "rt_build_blas: vertex index out of range");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = n_tris, max_nodes = 2 * n;  // a binary tree with >= 1 triangle per leaf has < 2n nodes
+  int r;
+  if ((r = ensure_buffer(c, c->bv_in, (size_t)n_verts * 16 + n * 12, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_order, n * 20, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_active, n * 8, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_out, max_nodes * 32, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_counters, 16, false)) < 0) return r;
+  float4* d_pos = (float4*)c->bv_in.ptr;
+  uint32_t* d_idx = (uint32_t*)((char*)c->bv_in.ptr + (size_t)n_verts * 16);
+  HIP_TRY(c, hipMemcpyAsync(d_pos, verts4, (size_t)n_verts * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_idx, indices, n * 12, hipMemcpyHostToDevice, c->stream));
+  float4* tri = (float4*)c->bv_tri.ptr;
+  uint32_t* ord = (uint32_t*)c->bv_order.ptr;
+  bvhb::Build B;
+  B.tri_mn = tri;
+  B.tri_mx = tri + n;
+  B.tri_c = tri + 2 * n;
+  B.order_in = ord;
+  B.order_out = ord + n;
+  B.order_final = ord + 2 * n;
+  B.scratch_l = ord + 3 * n;
+  B.scratch_r = ord + 4 * n;
+  B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
+  B.counters = (uint32_t*)c->bv_counters.ptr;
+  uint32_t* active[2] = {(uint32_t*)c->bv_active.ptr, (uint32_t*)c->bv_active.ptr + n};
+  hipLaunchKernelGGL(bvhb::k_tri_boxes, dim3((n_tris + 255) / 256), dim3(256), 0, c->stream, d_pos, d_idx, n_tris,
+                     (float4*)B.tri_mn, (float4*)B.tri_mx, (float4*)B.tri_c, B.order_in);
+  bvhb::BNode root;
+  std::memset(&root, 0, sizeof(root));
+  root.count = n_tris;
+  root.left = root.right = -1;
+  const uint32_t zero = 0, init_counters[2] = {1u, 0u};
+  HIP_TRY(c, hipMemcpyAsync(B.nodes, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(active[0], &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(B.counters, init_counters, 8, hipMemcpyHostToDevice, c->stream));
+  std::vector<std::pair<uint32_t, uint32_t>> levels;  // (first BFS id, node count) per level
+  uint32_t n_active = 1, id0 = 0, total = 1;
+  int cur = 0;
+  while (n_active) {
+    levels.emplace_back(id0, n_active);
+    if (levels.size() > (size_t)n_tris + 1) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: the tree is deeper than its triangle count");
+    hipLaunchKernelGGL(bvhb::k_level, dim3(n_active), dim3(256), 0, c->stream, B, (const uint32_t*)active[cur], n_active, active[1 - cur]);
+    uint32_t counters[2];
+    HIP_TRY(c, hipMemcpyAsync(counters, B.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    id0 = total;
+    total = counters[0];
+    n_active = counters[1];
+    if (total > max_nodes || total - id0 != n_active) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
+    HIP_TRY(c, hipMemsetAsync(B.counters + 1, 0, 4, c->stream));
+    std::swap(B.order_in, B.order_out);
+    cur = 1 - cur;
+  }
+  if (total > nodes_cap) return fail(c, RT_ERR_INVALID, "rt_build_blas: node buffer too small");
+  for (size_t l = levels.size(); l-- > 0;)
+    hipLaunchKernelGGL(bvhb::k_sizes, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, B.nodes, levels[l].first, levels[l].second);
+  for (size_t l = 0; l < levels.size(); l++)
+    hipLaunchKernelGGL(bvhb::k_preorder, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, B.nodes, levels[l].first, levels[l].second);
+  hipLaunchKernelGGL(bvhb::k_emit, dim3((total + 255) / 256), dim3(256), 0, c->stream, (const bvhb::BNode*)B.nodes, total, (float4*)c->bv_out.ptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(nodes_out, c->bv_out.ptr, (size_t)total * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(order_out, B.order_final, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n_nodes_out = total;
+  c->bv_levels = (uint32_t)levels.size();
   return RT_OK;
 }
 

@@ -42,8 +42,16 @@ inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-inline float fmin_nn(float a, float b) { return (b != b || a < b) ? a : b; }  // f32::min
-inline float fmax_nn(float a, float b) { return (b != b || a > b) ? a : b; }  // f32::max
+// f32::min / f32::max: a NaN operand loses; for zeros of opposite sign Rust leaves the result unspecified — here
+// -0 < +0 (the total order of the bit patterns), so that a chain of unions does not depend on the visiting order and
+// the GPU builder (csrc/bvh_build.hip.h), which reduces in parallel, lands on the same bits
+inline uint32_t fkey(float f) {
+  uint32_t b;
+  std::memcpy(&b, &f, 4);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float fmin_nn(float a, float b) { return (b != b) ? a : ((a != a) ? b : (fkey(b) < fkey(a) ? b : a)); }
+inline float fmax_nn(float a, float b) { return (b != b) ? a : ((a != a) ? b : (fkey(b) > fkey(a) ? b : a)); }
 inline V3 vmin(V3 a, V3 b) { return v3(fmin_nn(a.x, b.x), fmin_nn(a.y, b.y), fmin_nn(a.z, b.z)); }
 inline V3 vmax(V3 a, V3 b) { return v3(fmax_nn(a.x, b.x), fmax_nn(a.y, b.y), fmax_nn(a.z, b.z)); }
 inline float length(V3 a) { return std::sqrt(dot(a, a)); }
@@ -1057,6 +1065,9 @@ struct ms_world {
   // glTF scene graph (SceneData.nodes / skins / animations) and World.active_anim_index
   GltfScene gltf;
   size_t active_anim = 0;
+  // optional BLAS builder hook (ms_world_set_blas_builder): the GPU builder of libmi355rt.so
+  ms_blas_builder blas_hook = nullptr;
+  void* blas_hook_user = nullptr;
 };
 
 static thread_local std::string g_last_error;
@@ -1188,14 +1199,43 @@ static void world_update(ms_world& w, float time = 0.0f) {
       uv2.push_back(uv.x);
       uv2.push_back(uv.y);
     }
-    BlasBuilder bb(v4, geo.indices);
-    bb.build();
+    // BLAS: nodes (8 f32 each, BLAS-local skips) + triangle order, from the CPU builder or from the hook
+    std::vector<float> packed;
+    std::vector<uint32_t> order;
+    const uint32_t n_tris = (uint32_t)(geo.indices.size() / 3);
+    bool built = false;
+    if (w.blas_hook && n_tris) {
+      packed.resize((size_t)2 * n_tris * 8);
+      order.resize(n_tris);
+      uint32_t n_nodes = 0;
+      const int rc = w.blas_hook(w.blas_hook_user, v4.data(), (uint32_t)(v4.size() / 4), geo.indices.data(), n_tris, packed.data(),
+                                 2 * n_tris, &n_nodes, order.data());
+      if (rc >= 0) {
+        packed.resize((size_t)n_nodes * 8);
+        built = true;
+      } else {
+        g_last_error = "BLAS builder hook failed (" + std::to_string(rc) + "); the CPU builder was used for this update";
+      }
+    }
+    if (!built) {
+      BlasBuilder bb(v4, geo.indices);
+      bb.build();
+      packed.clear();
+      pack_nodes(bb.nodes, packed);
+      order.assign(bb.order.begin(), bb.order.end());
+    }
     uint32_t v_offset = (uint32_t)(w.vertices.size() / 4);
     uint32_t topo_start = (uint32_t)(w.topology.size() / 20);
-    for (BuildNode& n : bb.nodes)
-      if (n.data != 0) n.data = (((n.data >> 3) + topo_start) << 3) | (n.data & 7u);
-    for (size_t i = 0; i < bb.order.size(); i++) {
-      size_t old_id = bb.order[i];
+    for (size_t ni = 0; ni < packed.size() / 8; ni++) {  // leaf `first` becomes a global topology index (rebuilder.rs:123-134)
+      uint32_t data;
+      std::memcpy(&data, &packed[ni * 8 + 7], 4);
+      if (data != 0) {
+        data = (((data >> 3) + topo_start) << 3) | (data & 7u);
+        std::memcpy(&packed[ni * 8 + 7], &data, 4);
+      }
+    }
+    for (size_t i = 0; i < order.size(); i++) {
+      size_t old_id = order[i];
       uint32_t row[20];
       row[0] = geo.indices[old_id * 3] + v_offset;
       row[1] = geo.indices[old_id * 3 + 1] + v_offset;
@@ -1209,9 +1249,9 @@ static void world_update(ms_world& w, float time = 0.0f) {
     w.vertices.insert(w.vertices.end(), v4.begin(), v4.end());
     w.normals.insert(w.normals.end(), n4.begin(), n4.end());
     w.uvs.insert(w.uvs.end(), uv2.begin(), uv2.end());
-    pack_nodes(bb.nodes, w.blas);
+    w.blas.insert(w.blas.end(), packed.begin(), packed.end());
     w.blas_root_offsets.push_back(node_offset);
-    node_offset += (uint32_t)bb.nodes.size();
+    node_offset += (uint32_t)(packed.size() / 8);
     geom_ranges[gi] = {topo_start, (uint32_t)(w.topology.size() / 20) - topo_start};
   }
 
@@ -1336,7 +1376,9 @@ ms_world* ms_world_create_glb(const char* scene_name, const char* obj_source, co
 void ms_world_destroy(ms_world* w) { delete w; }
 
 void ms_world_update(ms_world* w, float time) {
-  if (w) world_update(*w, time);
+  if (!w) return;
+  g_last_error.clear();
+  world_update(*w, time);
 }
 
 size_t ms_world_animation_count(const ms_world* w) { return w ? w->gltf.animations.size() : 0; }
@@ -1358,6 +1400,11 @@ int ms_world_load_animation_glb(ms_world* w, const uint8_t* glb, size_t glb_size
   const int added = (int)tmp.animations.size();
   for (GAnimation& a : tmp.animations) w->gltf.animations.push_back(std::move(a));
   return added;
+}
+void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user) {
+  if (!w) return;
+  w->blas_hook = fn;
+  w->blas_hook_user = user;
 }
 size_t ms_world_node_count(const ms_world* w) { return w ? w->gltf.nodes.size() : 0; }
 size_t ms_world_encoded_texture_count(const ms_world* w) { return w ? w->scene.textures.size() : 0; }

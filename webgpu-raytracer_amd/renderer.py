@@ -40,6 +40,7 @@ def load_library(path=None):
         "rt_reset_accum": (i32, [vp]), "rt_upload_textures": (i32, [vp, vp, u32]),
         "rt_alloc_texture_layers": (i32, [vp, u32]), "rt_upload_texture_image": (i32, [vp, u32, vp, u32, u32]),
         "rt_read_texture_layer": (i32, [vp, u32, vp, ctypes.c_size_t]),
+        "rt_build_blas": (i32, [vp, vp, u32, vp, u32, vp, u32, ctypes.POINTER(u32), vp]),
         "rt_upload": (i32, [vp, i32, vp, ctypes.c_size_t]),
         "rt_upload_geometry": (i32, [vp, vp, vp, vp, u32]),
         "rt_upload_bvh": (i32, [vp, vp, u32, vp, u32]),
@@ -70,7 +71,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     "rt_create rt_destroy rt_last_error rt_set_pipeline rt_resize rt_reset_accum rt_upload_textures rt_upload "
-    "rt_alloc_texture_layers rt_upload_texture_image rt_read_texture_layer "
+    "rt_alloc_texture_layers rt_upload_texture_image rt_read_texture_layer rt_build_blas "
     "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_compute_batch rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum "
@@ -158,6 +159,18 @@ class WebGPURenderer:
         """Already decoded and resized (n, 1024, 1024, 4) uint8 layers (rt_upload_textures)."""
         a = np.ascontiguousarray(layers, dtype=np.uint8)
         self._check(self.L.rt_upload_textures(self.ctx, _ptr(a), a.shape[0]), "loadTextureLayers")
+
+    def buildBlas(self, verts4, indices):
+        """GPU binned-SAH BLAS build (rt_build_blas): returns (nodes (n, 8) float32, order (n_tris,) uint32)."""
+        v = np.ascontiguousarray(verts4, dtype=np.float32).reshape(-1, 4)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        n_tris = idx.size // 3
+        nodes = np.empty((max(1, 2 * n_tris), 8), dtype=np.float32)
+        order = np.empty(max(1, n_tris), dtype=np.uint32)
+        n_nodes = ctypes.c_uint32()
+        self._check(self.L.rt_build_blas(self.ctx, _ptr(v), v.shape[0], _ptr(idx), n_tris, _ptr(nodes), nodes.shape[0],
+                                         ctypes.byref(n_nodes), _ptr(order)), "buildBlas")
+        return nodes[:n_nodes.value].copy(), order[:n_tris].copy()
 
     def readTextureLayer(self, layer):
         out = np.empty((1024, 1024, 4), dtype=np.uint8)

@@ -52,6 +52,8 @@ def _load():
     lib.ms_world_load_animation_glb.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.ms_world_encoded_texture.restype = ctypes.POINTER(ctypes.c_uint8)
     lib.ms_world_encoded_texture.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.ms_world_set_blas_builder.restype = None
+    lib.ms_world_set_blas_builder.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.ms_world_texture_count.restype = ctypes.c_size_t
     lib.ms_world_texture_count.argtypes = [ctypes.c_void_p]
     lib.ms_world_texture_rgba.restype = ctypes.POINTER(ctypes.c_uint8)
@@ -68,6 +70,7 @@ class WorldBridge:
         self._world = None
         self._cache = {}
         self._tex_blobs = {}
+        self._blas_renderer = None
         self.hasNewData = False
         self.hasNewGeometry = False
         self._last_wh = (-1, -1)
@@ -94,15 +97,37 @@ class WorldBridge:
         # a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
         self.loadWarning = self._lib.ms_last_error().decode() if glbData is not None else ""
         self._world = w
+        self._apply_blas_builder()
         self._tex_blobs = {}
         self._last_wh = (-1, -1)
         self._refresh()
         self.hasNewData = True
         self.hasNewGeometry = True
 
+    def setBlasBuilder(self, renderer):
+        """Run the per-geometry BLAS build of update(t) on the GPU: `renderer` is a WebGPURenderer whose rt_build_blas
+        returns the CPU builder's tree byte for byte; None restores the CPU builder.  The hook is a
+        C function pointer handed to the scene compiler — no Python in the loop."""
+        self._blas_renderer = renderer
+        self._apply_blas_builder()
+
+    def _apply_blas_builder(self):
+        if not self._world:
+            return
+        r = self._blas_renderer
+        if r is None:
+            self._lib.ms_world_set_blas_builder(self._world, None, None)
+        else:
+            fn = ctypes.cast(r.L.rt_build_blas, ctypes.c_void_p)
+            self._lib.ms_world_set_blas_builder(self._world, fn, r.ctx)
+
     # world-bridge.ts:141-145
     def update(self, time):
         self._lib.ms_world_update(self._world, float(time))
+        if self._blas_renderer is not None:
+            err = self._lib.ms_last_error().decode()
+            if err:
+                raise RuntimeError(err)      # the GPU builder failed: no silent CPU result
         self._refresh()
         self.hasNewData = True
         self.hasNewGeometry = True
