@@ -28,7 +28,6 @@
 
 namespace bvhb {
 
-constexpr int kThreads = 256;
 constexpr int kBins = 16;
 
 struct BNode {  // breadth-first build record
@@ -50,7 +49,7 @@ struct Build {
   uint32_t* scratch_l;   // positions of misplaced elements, by rank
   uint32_t* scratch_r;
   BNode* nodes;
-  uint32_t* counters;    // [0] next node id, [1] nodes appended to the next level
+  uint32_t* counters;    // [0] next node id
 };
 
 __device__ __forceinline__ uint32_t key_of(float f) {  // order-preserving: a < b  <=>  key(a) < key(b); -0 < +0
@@ -99,7 +98,8 @@ __device__ __forceinline__ float area_of(const float mn[3], const float mx[3]) {
   return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
 
-// exclusive prefix sum of a flag over the 256 threads of the block; returns this thread's rank and the block total
+// exclusive prefix sum of a flag over the T threads of the block; returns this thread's rank and the block total
+template <int T>
 __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_wave, uint32_t& total) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long m = __ballot(flag);
@@ -107,23 +107,82 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_wave, uint
   __syncthreads();  // s_wave may still be read by the previous call
   if (lane == 0u) s_wave[wave] = (uint32_t)__builtin_popcountll(m);
   __syncthreads();
-  uint32_t before = 0;
-  for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
-  total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  uint32_t before = 0, all = 0;
+  for (uint32_t w = 0; w < (uint32_t)(T / 64); w++) {
+    const uint32_t v = s_wave[w];
+    before += w < wave ? v : 0u;
+    all += v;
+  }
+  total = all;
   return before + in_wave;
 }
 
-__global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restrict__ active_in, uint32_t n_active,
-                                                uint32_t* __restrict__ active_out) {
-  __shared__ uint32_t s_red[4][6];
+// blas.rs:149-177 + 201-217 for one node from its bins: best split, left count, child order
+__device__ __forceinline__ void sah_split(const uint32_t* bin_cnt, const uint32_t (*bin_box)[6], uint32_t count, int& leaf, int& split,
+                                          uint32_t& L, int& rotate) {
+  float l_area[kBins], r_area[kBins];
+  uint32_t l_cnt[kBins], r_cnt[kBins];
+  const float inf = __uint_as_float(0x7f800000u);
+  float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+  uint32_t sum = 0;
+  for (int i = 0; i < kBins; i++) {
+    sum += bin_cnt[i];
+    for (int c = 0; c < 3; c++) {
+      const float bmn = bin_cnt[i] ? float_of(bin_box[i][c]) : inf, bmx = bin_cnt[i] ? float_of(bin_box[i][c + 3]) : -inf;
+      cmn[c] = tmin(cmn[c], bmn);
+      cmx[c] = tmax(cmx[c], bmx);
+    }
+    l_area[i] = area_of(cmn, cmx);
+    l_cnt[i] = sum;
+  }
+  for (int c = 0; c < 3; c++) { cmn[c] = inf; cmx[c] = -inf; }
+  sum = 0;
+  for (int i = kBins - 1; i >= 0; i--) {
+    sum += bin_cnt[i];
+    for (int c = 0; c < 3; c++) {
+      const float bmn = bin_cnt[i] ? float_of(bin_box[i][c]) : inf, bmx = bin_cnt[i] ? float_of(bin_box[i][c + 3]) : -inf;
+      cmn[c] = tmin(cmn[c], bmn);
+      cmx[c] = tmax(cmx[c], bmx);
+    }
+    r_area[i] = area_of(cmn, cmx);
+    r_cnt[i] = sum;
+  }
+  float best = inf;
+  int best_split = -1;
+  for (int i = 0; i < kBins - 1; i++) {
+    if (l_cnt[i] == 0u || r_cnt[i + 1] == 0u) continue;
+    const float cost = l_area[i] * (float)l_cnt[i] + r_area[i + 1] * (float)r_cnt[i + 1];
+    if (cost < best) {
+      best = cost;
+      best_split = i;
+    }
+  }
+  leaf = best_split < 0;
+  L = 0;
+  rotate = 0;
+  if (!leaf) {
+    L = l_cnt[best_split];
+    if (L == 0u || L == count) leaf = 1;
+    const float l_cost = l_area[best_split] * (float)L, r_cost = r_area[best_split + 1] * (float)(count - L);
+    rotate = r_cost > l_cost;  // the costlier child goes first
+  }
+  split = best_split;
+}
+
+// T = 1024 for the first levels (few, large nodes: one workgroup walks up to the whole mesh, so it needs all the waves a
+// CU can hold to hide the order -> triangle gathers), 256 below
+template <int T>
+__global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict__ ids, uint32_t id0, uint32_t n_active) {
+  constexpr uint32_t kThreads = (uint32_t)T;
+  __shared__ uint32_t s_red[T / 64][6];
   __shared__ uint32_t s_bin_cnt[kBins];
   __shared__ uint32_t s_bin_box[kBins][6];
-  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_wave[T / 64];
   __shared__ float s_f[2];        // split_min, scale
   __shared__ int32_t s_i[6];      // leaf flag, axis, best split, L, rotate, nbad
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= n_active) return;
-  const uint32_t id = active_in[blockIdx.x];
+  const uint32_t id = ids ? ids[blockIdx.x] : id0 + blockIdx.x;  // the BFS ids of a level are contiguous
   const uint32_t first = B.nodes[id].first, count = B.nodes[id].count, end = first + count;
 
   // ---- 1. box of the range
@@ -145,8 +204,13 @@ __global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restri
   if (tid == 0u) {
     float mn[3], mx[3];
     for (int c = 0; c < 3; c++) {
-      mn[c] = float_of(min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c])));
-      mx[c] = float_of(max(max(s_red[0][c + 3], s_red[1][c + 3]), max(s_red[2][c + 3], s_red[3][c + 3])));
+      uint32_t kmn = s_red[0][c], kmx = s_red[0][c + 3];
+      for (int w = 1; w < T / 64; w++) {
+        kmn = min(kmn, s_red[w][c]);
+        kmx = max(kmx, s_red[w][c + 3]);
+      }
+      mn[c] = float_of(kmn);
+      mx[c] = float_of(kmx);
       B.nodes[id].mn[c] = mn[c];
       B.nodes[id].mx[c] = mx[c];
     }
@@ -181,57 +245,13 @@ __global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restri
       atomicMax(&s_bin_box[b][3], key_of(c.x)); atomicMax(&s_bin_box[b][4], key_of(c.y)); atomicMax(&s_bin_box[b][5], key_of(c.z));
     }
     __syncthreads();
-    // ---- 3. SAH sweep (blas.rs:149-177)
+    // ---- 3. SAH sweep and split choice (blas.rs:149-177, 201-217)
     if (tid == 0u) {
-      float l_area[kBins], r_area[kBins];
-      uint32_t l_cnt[kBins], r_cnt[kBins];
-      const float inf = __uint_as_float(0x7f800000u);
-      float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
-      uint32_t sum = 0;
-      for (int i = 0; i < kBins; i++) {
-        sum += s_bin_cnt[i];
-        for (int c = 0; c < 3; c++) {
-          // an untouched bin decodes to NaN-free sentinels only through the keys: compare keys, not floats
-          const float bmn = s_bin_cnt[i] ? float_of(s_bin_box[i][c]) : inf, bmx = s_bin_cnt[i] ? float_of(s_bin_box[i][c + 3]) : -inf;
-          cmn[c] = tmin(cmn[c], bmn);
-          cmx[c] = tmax(cmx[c], bmx);
-        }
-        l_area[i] = area_of(cmn, cmx);
-        l_cnt[i] = sum;
-      }
-      for (int c = 0; c < 3; c++) { cmn[c] = inf; cmx[c] = -inf; }
-      sum = 0;
-      for (int i = kBins - 1; i >= 0; i--) {
-        sum += s_bin_cnt[i];
-        for (int c = 0; c < 3; c++) {
-          const float bmn = s_bin_cnt[i] ? float_of(s_bin_box[i][c]) : inf, bmx = s_bin_cnt[i] ? float_of(s_bin_box[i][c + 3]) : -inf;
-          cmn[c] = tmin(cmn[c], bmn);
-          cmx[c] = tmax(cmx[c], bmx);
-        }
-        r_area[i] = area_of(cmn, cmx);
-        r_cnt[i] = sum;
-      }
-      float best = inf;
-      int best_split = -1;
-      for (int i = 0; i < kBins - 1; i++) {
-        if (l_cnt[i] == 0u || r_cnt[i + 1] == 0u) continue;
-        const float cost = l_area[i] * (float)l_cnt[i] + r_area[i + 1] * (float)r_cnt[i + 1];
-        if (cost < best) {
-          best = cost;
-          best_split = i;
-        }
-      }
-      int leaf = best_split < 0;
-      uint32_t L = 0;
-      int rotate = 0;
-      if (!leaf) {
-        L = l_cnt[best_split];
-        if (L == 0u || L == count) leaf = 1;
-        const float l_cost = l_area[best_split] * (float)L, r_cost = r_area[best_split + 1] * (float)(count - L);
-        rotate = r_cost > l_cost;   // blas.rs:209-217: the costlier child goes first
-      }
+      int leaf, split, rotate;
+      uint32_t L;
+      sah_split(s_bin_cnt, s_bin_box, count, leaf, split, L, rotate);
       s_i[0] = leaf;
-      s_i[2] = best_split;
+      s_i[2] = split;
       s_i[3] = (int32_t)L;
       s_i[4] = rotate;
     }
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restri
     bool bad = false;
     if (base + tid < L) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) > split;
     uint32_t total;
-    const uint32_t r = block_rank(bad, s_wave, total);
+    const uint32_t r = block_rank<T>(bad, s_wave, total);
     if (bad) B.scratch_l[first + run_l + r] = p;
     run_l += total;
   }
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restri
     bool bad = false;
     if (base + tid < R) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) <= split;
     uint32_t total;
-    const uint32_t r = block_rank(bad, s_wave, total);
+    const uint32_t r = block_rank<T>(bad, s_wave, total);
     if (bad) B.scratch_r[first + run_r + r] = p;
     run_r += total;
   }
@@ -291,9 +311,245 @@ __global__ __launch_bounds__(256) void k_level(Build B, const uint32_t* __restri
     B.nodes[ids + 1u].count = count - l_count;
     B.nodes[id].left = (int32_t)ids;
     B.nodes[id].right = (int32_t)(ids + 1u);
-    const uint32_t slot = atomicAdd(&B.counters[1], 2u);
-    active_out[slot] = ids;
-    active_out[slot + 1u] = ids + 1u;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------- large nodes
+// A node with more than kBig triangles is worked on by many workgroups: its range is cut into chunks of kChunk
+// positions and every step of k_level becomes its own launch over all chunks of all large nodes of the level
+// (bounds -> setup -> bins -> split -> count -> scan -> scatter -> swap -> copy).  Same arithmetic, same result.
+constexpr uint32_t kBig = 4096u;
+constexpr uint32_t kChunk = 2048u;
+
+struct BigNode {
+  uint32_t id, first, count, chunk0, nchunks;
+  int32_t leaf, axis, split, rotate;
+  uint32_t L, nbad;
+  float split_min, scale;
+  uint32_t box[6];
+  uint32_t bin_cnt[kBins];
+  uint32_t bin_box[kBins][6];
+};
+struct Chunk {
+  uint32_t big, j;  // index into the level's BigNode array, chunk index inside the node
+};
+
+__global__ __launch_bounds__(256) void k_big_bounds(Build B, BigNode* bn, const Chunk* __restrict__ chunks) {
+  __shared__ uint32_t s_red[4][6];
+  const Chunk ch = chunks[blockIdx.x];
+  BigNode& N = bn[ch.big];
+  const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count);
+  uint32_t k[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
+    const uint32_t t = B.order_in[p];
+    const float4 a = B.tri_mn[t], b = B.tri_mx[t];
+    k[0] = min(k[0], key_of(a.x)); k[1] = min(k[1], key_of(a.y)); k[2] = min(k[2], key_of(a.z));
+    k[3] = max(k[3], key_of(b.x)); k[4] = max(k[4], key_of(b.y)); k[5] = max(k[5], key_of(b.z));
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int c = 0; c < 6; c++) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)k[c], off, 64);
+      k[c] = c < 3 ? min(k[c], o) : max(k[c], o);
+    }
+  if ((threadIdx.x & 63u) == 0u)
+    for (int c = 0; c < 6; c++) s_red[threadIdx.x >> 6][c] = k[c];
+  __syncthreads();
+  if (threadIdx.x < 6u) {
+    const uint32_t c = threadIdx.x;
+    if (c < 3u) atomicMin(&N.box[c], min(min(s_red[0][c], s_red[1][c]), min(s_red[2][c], s_red[3][c])));
+    else atomicMax(&N.box[c], max(max(s_red[0][c], s_red[1][c]), max(s_red[2][c], s_red[3][c])));
+  }
+}
+
+__global__ __launch_bounds__(64) void k_big_setup(Build B, BigNode* bn, uint32_t n_big) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n_big) return;
+  BigNode& N = bn[i];
+  float mn[3], mx[3];
+  for (int c = 0; c < 3; c++) {
+    mn[c] = float_of(N.box[c]);
+    mx[c] = float_of(N.box[c + 3]);
+    B.nodes[N.id].mn[c] = mn[c];
+    B.nodes[N.id].mx[c] = mx[c];
+  }
+  const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+  const int axis = ey > ex ? 1 : ((ez > ex && ez > ey) ? 2 : 0);
+  const float split_len = axis == 0 ? ex : (axis == 1 ? ey : ez);
+  N.leaf = (N.count <= 4u || split_len < 1e-6f) ? 1 : 0;
+  N.axis = axis;
+  N.split_min = mn[axis];
+  N.scale = (float)kBins / split_len;
+}
+
+__global__ __launch_bounds__(256) void k_big_bin(Build B, BigNode* bn, const Chunk* __restrict__ chunks) {
+  __shared__ uint32_t s_cnt[kBins];
+  __shared__ uint32_t s_box[kBins][6];
+  const Chunk ch = chunks[blockIdx.x];
+  BigNode& N = bn[ch.big];
+  if (N.leaf) return;
+  if (threadIdx.x < (uint32_t)kBins) {
+    s_cnt[threadIdx.x] = 0u;
+    for (int c = 0; c < 3; c++) {
+      s_box[threadIdx.x][c] = 0xffffffffu;
+      s_box[threadIdx.x][c + 3] = 0u;
+    }
+  }
+  __syncthreads();
+  const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count);
+  const int axis = N.axis;
+  const float split_min = N.split_min, scale = N.scale;
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
+    const uint32_t t = B.order_in[p];
+    const uint32_t b = bin_of(axis_of(B.tri_c[t], axis), split_min, scale);
+    const float4 a = B.tri_mn[t], c = B.tri_mx[t];
+    atomicAdd(&s_cnt[b], 1u);
+    atomicMin(&s_box[b][0], key_of(a.x)); atomicMin(&s_box[b][1], key_of(a.y)); atomicMin(&s_box[b][2], key_of(a.z));
+    atomicMax(&s_box[b][3], key_of(c.x)); atomicMax(&s_box[b][4], key_of(c.y)); atomicMax(&s_box[b][5], key_of(c.z));
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)kBins && s_cnt[threadIdx.x]) {
+    const uint32_t b = threadIdx.x;
+    atomicAdd(&N.bin_cnt[b], s_cnt[b]);
+    for (int c = 0; c < 3; c++) {
+      atomicMin(&N.bin_box[b][c], s_box[b][c]);
+      atomicMax(&N.bin_box[b][c + 3], s_box[b][c + 3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_big_split(BigNode* bn, uint32_t n_big) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n_big) return;
+  BigNode& N = bn[i];
+  if (N.leaf) return;
+  int leaf, split, rotate;
+  uint32_t L;
+  sah_split(N.bin_cnt, N.bin_box, N.count, leaf, split, L, rotate);
+  N.leaf = leaf;
+  N.split = split;
+  N.L = L;
+  N.rotate = rotate;
+}
+
+// misplaced elements per chunk: left-region positions (< first + L) that belong right, right-region ones that belong left
+__global__ __launch_bounds__(256) void k_big_count(Build B, const BigNode* __restrict__ bn, const Chunk* __restrict__ chunks,
+                                                    uint32_t* __restrict__ chunk_cnt) {
+  __shared__ uint32_t s_c[2];
+  const Chunk ch = chunks[blockIdx.x];
+  const BigNode& N = bn[ch.big];
+  if (N.leaf) return;
+  if (threadIdx.x < 2u) s_c[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count), mid = N.first + N.L;
+  uint32_t cl = 0, cr = 0;
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
+    const bool right = bin_of(axis_of(B.tri_c[B.order_in[p]], N.axis), N.split_min, N.scale) > (uint32_t)N.split;
+    cl += (p < mid && right) ? 1u : 0u;
+    cr += (p >= mid && !right) ? 1u : 0u;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cl += (uint32_t)__shfl_xor((int)cl, off, 64);
+    cr += (uint32_t)__shfl_xor((int)cr, off, 64);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicAdd(&s_c[0], cl);
+    atomicAdd(&s_c[1], cr);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2u) chunk_cnt[2 * (N.chunk0 + ch.j) + threadIdx.x] = s_c[threadIdx.x];
+}
+
+// rank bases per chunk: misplaced-left ranks grow with the position, misplaced-right ranks grow towards the left
+__global__ __launch_bounds__(64) void k_big_scan(BigNode* bn, uint32_t n_big, const uint32_t* __restrict__ chunk_cnt,
+                                                  uint32_t* __restrict__ chunk_base) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n_big) return;
+  BigNode& N = bn[i];
+  if (N.leaf) return;
+  uint32_t run = 0;
+  for (uint32_t j = 0; j < N.nchunks; j++) {
+    chunk_base[2 * (N.chunk0 + j)] = run;
+    run += chunk_cnt[2 * (N.chunk0 + j)];
+  }
+  N.nbad = run;
+  run = 0;
+  for (uint32_t j = N.nchunks; j-- > 0;) {
+    chunk_base[2 * (N.chunk0 + j) + 1] = run;
+    run += chunk_cnt[2 * (N.chunk0 + j) + 1];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_scatter(Build B, const BigNode* __restrict__ bn, const Chunk* __restrict__ chunks,
+                                                      const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_base) {
+  __shared__ uint32_t s_wave[4];
+  const Chunk ch = chunks[blockIdx.x];
+  const BigNode& N = bn[ch.big];
+  if (N.leaf) return;
+  const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count), mid = N.first + N.L;
+  const uint32_t cidx = N.chunk0 + ch.j;
+  const uint32_t base_l = chunk_base[2 * cidx], base_r = chunk_base[2 * cidx + 1], tot_r = chunk_cnt[2 * cidx + 1];
+  uint32_t run_l = 0, run_r = 0;
+  for (uint32_t q = lo; q < hi; q += 256u) {
+    const uint32_t p = q + threadIdx.x;
+    bool bl = false, br = false;
+    if (p < hi) {
+      const bool right = bin_of(axis_of(B.tri_c[B.order_in[p]], N.axis), N.split_min, N.scale) > (uint32_t)N.split;
+      bl = p < mid && right;
+      br = p >= mid && !right;
+    }
+    uint32_t total;
+    uint32_t r = block_rank<256>(bl, s_wave, total);
+    if (bl) B.scratch_l[N.first + base_l + run_l + r] = p;
+    run_l += total;
+    r = block_rank<256>(br, s_wave, total);
+    // ranks of the right region count from the node's right end: inside the chunk the highest position comes first
+    if (br) B.scratch_r[N.first + base_r + (tot_r - 1u - (run_r + r))] = p;
+    run_r += total;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_swap(Build B, const BigNode* __restrict__ bn, const Chunk* __restrict__ chunks) {
+  const Chunk ch = chunks[blockIdx.x];
+  const BigNode& N = bn[ch.big];
+  if (N.leaf) return;
+  const uint32_t hi = min((ch.j + 1u) * kChunk, N.nbad);
+  for (uint32_t q = ch.j * kChunk + threadIdx.x; q < hi; q += 256u) {
+    const uint32_t a = B.scratch_l[N.first + q], b = B.scratch_r[N.first + q];
+    const uint32_t ta = B.order_in[a], tb = B.order_in[b];
+    B.order_in[a] = tb;
+    B.order_in[b] = ta;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_copy(Build B, const BigNode* __restrict__ bn, const Chunk* __restrict__ chunks) {
+  const Chunk ch = chunks[blockIdx.x];
+  const BigNode& N = bn[ch.big];
+  const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count);
+  if (N.leaf) {
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) B.order_final[p] = B.order_in[p];
+    if (ch.j == 0u && threadIdx.x == 0u) {
+      B.nodes[N.id].left = -1;
+      B.nodes[N.id].right = -1;
+    }
+    return;
+  }
+  const uint32_t L = N.L, R = N.count - N.L;
+  const bool rotate = N.rotate != 0;
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
+    const uint32_t rel = p - N.first;
+    const uint32_t nrel = rotate ? (rel >= L ? rel - L : rel + R) : rel;
+    B.order_out[N.first + nrel] = B.order_in[p];
+  }
+  if (ch.j == 0u && threadIdx.x == 0u) {
+    const uint32_t l_count = rotate ? R : L;
+    const uint32_t ids = atomicAdd(&B.counters[0], 2u);
+    B.nodes[ids].first = N.first;
+    B.nodes[ids].count = l_count;
+    B.nodes[ids + 1u].first = N.first + l_count;
+    B.nodes[ids + 1u].count = N.count - l_count;
+    B.nodes[N.id].left = (int32_t)ids;
+    B.nodes[N.id].right = (int32_t)(ids + 1u);
   }
 }
 

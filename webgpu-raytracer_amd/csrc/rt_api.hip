@@ -46,7 +46,7 @@ struct rt_ctx {
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
   uint32_t bv_levels = 0;
-  DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters;  // rt_build_blas work space
+  DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
@@ -323,7 +323,7 @@ void rt_destroy(rt_ctx* c) {
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
-                         &c->bv_counters};
+                         &c->bv_counters, &c->bv_big};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -467,7 +467,7 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_order, n * 20, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_active, n * 8, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_active, n * 4, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_out, max_nodes * 32, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_counters, 16, false)) < 0) return r;
   float4* d_pos = (float4*)c->bv_in.ptr;
@@ -487,35 +487,91 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   B.scratch_r = ord + 4 * n;
   B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
   B.counters = (uint32_t*)c->bv_counters.ptr;
-  uint32_t* active[2] = {(uint32_t*)c->bv_active.ptr, (uint32_t*)c->bv_active.ptr + n};
+  uint32_t* d_ids = (uint32_t*)c->bv_active.ptr;
   hipLaunchKernelGGL(bvhb::k_tri_boxes, dim3((n_tris + 255) / 256), dim3(256), 0, c->stream, d_pos, d_idx, n_tris,
                      (float4*)B.tri_mn, (float4*)B.tri_mx, (float4*)B.tri_c, B.order_in);
   bvhb::BNode root;
   std::memset(&root, 0, sizeof(root));
   root.count = n_tris;
   root.left = root.right = -1;
-  const uint32_t zero = 0, init_counters[2] = {1u, 0u};
+  const uint32_t one = 1u;
   HIP_TRY(c, hipMemcpyAsync(B.nodes, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(active[0], &zero, 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(B.counters, init_counters, 8, hipMemcpyHostToDevice, c->stream));
-  std::vector<std::pair<uint32_t, uint32_t>> levels;  // (first BFS id, node count) per level
+  HIP_TRY(c, hipMemcpyAsync(B.counters, &one, 4, hipMemcpyHostToDevice, c->stream));
+  std::vector<std::pair<uint32_t, uint32_t>> levels;  // (first BFS id, node count) per level: the ids of a level are contiguous
   uint32_t n_active = 1, id0 = 0, total = 1;
-  int cur = 0;
+  bool big_possible = n_tris > bvhb::kBig;
+  std::vector<bvhb::BNode> host_nodes;
+  std::vector<bvhb::BigNode> big;
+  std::vector<bvhb::Chunk> chunks;
+  std::vector<uint32_t> small_ids;
   while (n_active) {
     levels.emplace_back(id0, n_active);
     if (levels.size() > (size_t)n_tris + 1) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: the tree is deeper than its triangle count");
-    hipLaunchKernelGGL(bvhb::k_level, dim3(n_active), dim3(256), 0, c->stream, B, (const uint32_t*)active[cur], n_active, active[1 - cur]);
-    uint32_t counters[2];
-    HIP_TRY(c, hipMemcpyAsync(counters, B.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    big.clear();
+    chunks.clear();
+    small_ids.clear();
+    if (big_possible) {
+      // the few nodes of the first levels: those above kBig triangles are cut into chunks and worked on by many workgroups
+      host_nodes.resize(n_active);
+      HIP_TRY(c, hipMemcpyAsync(host_nodes.data(), B.nodes + id0, (size_t)n_active * sizeof(bvhb::BNode), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (uint32_t i = 0; i < n_active; i++) {
+        if (host_nodes[i].count > bvhb::kBig) {
+          bvhb::BigNode N;
+          std::memset(&N, 0, sizeof(N));
+          N.id = id0 + i;
+          N.first = host_nodes[i].first;
+          N.count = host_nodes[i].count;
+          N.chunk0 = (uint32_t)chunks.size();
+          N.nchunks = (N.count + bvhb::kChunk - 1) / bvhb::kChunk;
+          for (int k = 0; k < 3; k++) N.box[k] = 0xffffffffu;
+          for (int bi = 0; bi < bvhb::kBins; bi++)
+            for (int k = 0; k < 3; k++) N.bin_box[bi][k] = 0xffffffffu;
+          for (uint32_t j = 0; j < N.nchunks; j++) chunks.push_back(bvhb::Chunk{(uint32_t)big.size(), j});
+          big.push_back(N);
+        } else {
+          small_ids.push_back(id0 + i);
+        }
+      }
+      if (big.empty()) big_possible = false;  // children are never larger than their parent
+    }
+    if (!big.empty()) {
+      const uint32_t nb = (uint32_t)big.size(), nc = (uint32_t)chunks.size();
+      if ((r = ensure_buffer(c, c->bv_big, (size_t)nb * sizeof(bvhb::BigNode) + (size_t)nc * (sizeof(bvhb::Chunk) + 16), false)) < 0) return r;
+      bvhb::BigNode* d_big = (bvhb::BigNode*)c->bv_big.ptr;
+      bvhb::Chunk* d_chunks = (bvhb::Chunk*)(d_big + nb);
+      uint32_t* d_cnt = (uint32_t*)(d_chunks + nc);
+      uint32_t* d_base = d_cnt + 2 * (size_t)nc;
+      HIP_TRY(c, hipMemcpyAsync(d_big, big.data(), (size_t)nb * sizeof(bvhb::BigNode), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(d_chunks, chunks.data(), (size_t)nc * sizeof(bvhb::Chunk), hipMemcpyHostToDevice, c->stream));
+      const dim3 gn((nb + 63) / 64), gc(nc);
+      hipLaunchKernelGGL(bvhb::k_big_bounds, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_setup, gn, dim3(64), 0, c->stream, B, d_big, nb);
+      hipLaunchKernelGGL(bvhb::k_big_bin, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_split, gn, dim3(64), 0, c->stream, d_big, nb);
+      hipLaunchKernelGGL(bvhb::k_big_count, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks, d_cnt);
+      hipLaunchKernelGGL(bvhb::k_big_scan, gn, dim3(64), 0, c->stream, d_big, nb, (const uint32_t*)d_cnt, d_base);
+      hipLaunchKernelGGL(bvhb::k_big_scatter, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks,
+                         (const uint32_t*)d_cnt, (const uint32_t*)d_base);
+      hipLaunchKernelGGL(bvhb::k_big_swap, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_copy, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
+      if (!small_ids.empty()) {
+        HIP_TRY(c, hipMemcpyAsync(d_ids, small_ids.data(), small_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bvhb::k_level<256>, dim3((uint32_t)small_ids.size()), dim3(256), 0, c->stream, B, (const uint32_t*)d_ids, 0u,
+                           (uint32_t)small_ids.size());
+      }
+    } else {
+      hipLaunchKernelGGL(bvhb::k_level<256>, dim3(n_active), dim3(256), 0, c->stream, B, (const uint32_t*)nullptr, id0, n_active);
+    }
+    uint32_t next_total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&next_total, B.counters, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (next_total > max_nodes || next_total < total) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
     id0 = total;
-    total = counters[0];
-    n_active = counters[1];
-    if (total > max_nodes || total - id0 != n_active) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
-    HIP_TRY(c, hipMemsetAsync(B.counters + 1, 0, 4, c->stream));
+    n_active = next_total - total;
+    total = next_total;
     std::swap(B.order_in, B.order_out);
-    cur = 1 - cur;
   }
   if (total > nodes_cap) return fail(c, RT_ERR_INVALID, "rt_build_blas: node buffer too small");
   for (size_t l = levels.size(); l-- > 0;)
