@@ -91,8 +91,9 @@ def test_javascript_bridge_hands_out_png_that_decodes_to_the_layer(W, addon):
 @pytest.mark.gpu
 def test_javascript_textured_render_matches_the_oracle(W, oracle_lib, addon):
     """sponza_like from JS: loadTexturesFromWorld = PNG -> mtDecode -> rtUploadTextureImage (GPU resize)."""
+    env = dict(os.environ, RT_NODE_GPU_BLAS="1")       # and the 263k-triangle BLAS rebuilt by rt_build_blas through the bridge hook
     out = subprocess.run([node, os.path.join(NODE_DIR, "render_cornell.js"), "sponza_like", "64", "40", "2", "5"],
-                         check=True, capture_output=True, text=True, timeout=600).stdout
+                         check=True, capture_output=True, text=True, timeout=600, env=env).stdout
     got = json.loads(out.strip().splitlines()[-1])
     b = W.WorldBridge()
     b.loadScene("sponza_like")

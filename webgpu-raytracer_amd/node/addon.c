@@ -373,6 +373,16 @@ static napi_value msLoadAnimation(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 2, a) || !get_bytes(env, a[1], &p, &n)) return NULL;
   return make_int(env, ms_world_load_animation_glb((ms_world*)get_ptr(env, a[0]), (const uint8_t*)p, n));
 }
+/* (world, ctx | null): World::update(t) builds its BLASes with rt_build_blas (GPU) instead of the CPU builder */
+static napi_value msSetBlasBuilder(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  napi_valuetype vt;
+  napi_typeof(env, a[1], &vt);
+  void* ctx = vt == napi_external ? get_ptr(env, a[1]) : NULL;
+  ms_world_set_blas_builder((ms_world*)get_ptr(env, a[0]), ctx ? (ms_blas_builder)rt_build_blas : NULL, ctx);
+  return NULL;
+}
 static napi_value msLastError(napi_env env, napi_callback_info info) {
   napi_value s;
   (void)info;
@@ -432,7 +442,7 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"msUpdate", msUpdate}, {"msUpdateCamera", msUpdateCamera}, {"msGet", msGet},
                {"msTextureCount", msTextureCount}, {"msTexture", msTexture},
                {"msAnimationNames", msAnimationNames}, {"msSetAnimation", msSetAnimation},
-               {"msLoadAnimation", msLoadAnimation}, {"msLastError", msLastError},
+               {"msLoadAnimation", msLoadAnimation}, {"msLastError", msLastError}, {"msSetBlasBuilder", msSetBlasBuilder},
                {"msEncodedTextureCount", msEncodedTextureCount}, {"msEncodedTexture", msEncodedTexture}};
   for (size_t i = 0; i < sizeof(table) / sizeof(table[0]); i++) {
     napi_value fn;

@@ -42,6 +42,8 @@ export class WorldBridge {
   readonly textureCount: number;
   readonly hasWorld: boolean;
   getTextureRGBA(index: number): Uint8Array | undefined;
+  /** build the BLASes of update(t) on the GPU with this renderer (same tree as the CPU builder); null restores the CPU builder */
+  setBlasBuilder(renderer: WebGPURenderer | null): void;
   getAnimationList(): string[];
   loadAnimation(data: Uint8Array): number;
   setAnimation(index: number): void;

@@ -136,12 +136,25 @@ class WorldBridge {
     this._w = native.msCreate(sceneName, objSource === undefined ? null : objSource, glbData || null);
     // a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
     this.loadWarning = glbData ? native.msLastError() : '';
+    if (this._blasRenderer) native.msSetBlasBuilder(this._w, this._blasRenderer._ctx);
     this._wh = [-1, -1];
     this._refresh();
     this.hasNewData = true;
     this.hasNewGeometry = true;
   }
-  update(time) { native.msUpdate(this._w, time); this._refresh(); this.hasNewData = true; this.hasNewGeometry = true; }
+  update(time) {
+    native.msUpdate(this._w, time);
+    if (this._blasRenderer) {
+      const err = native.msLastError();
+      if (err) throw new Error(err);   // the GPU builder failed: no silent CPU result
+    }
+    this._refresh(); this.hasNewData = true; this.hasNewGeometry = true;
+  }
+  // build the BLASes of update(t) on the GPU (rt_build_blas: the CPU builder's tree, byte for byte); null = CPU builder
+  setBlasBuilder(renderer) {
+    this._blasRenderer = renderer || null;
+    if (this._w) native.msSetBlasBuilder(this._w, renderer ? renderer._ctx : null);
+  }
   updateCamera(width, height) {
     if (this._wh[0] === width && this._wh[1] === height) return;
     this._wh = [width, height];

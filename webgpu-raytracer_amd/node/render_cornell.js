@@ -14,6 +14,10 @@ const { WebGPURenderer, WorldBridge } = require('./index.js');
   const renderer = new WebGPURenderer(0);
   await renderer.init();
   renderer.buildPipeline(parseInt(depth, 10), 1);
+  if (process.env.RT_NODE_GPU_BLAS) {  // rebuild the scene's BLASes with the GPU builder (same arrays, byte for byte)
+    bridge.setBlasBuilder(renderer);
+    bridge.update(0);
+  }
   await renderer.loadTexturesFromWorld(bridge);
   renderer.updateCombinedGeometry(bridge.vertices, bridge.normals, bridge.uvs);
   renderer.updateCombinedBVH(bridge.tlas, bridge.blas);
