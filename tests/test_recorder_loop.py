@@ -65,3 +65,43 @@ def test_recorder_loop_image_parity(W, oracle_lib):
     assert ga[..., 3].max() == 7.0                  # N-1 samples: frames 0 and 1 both overwrite
     for g, c in zip(gf, cf):
         assert np.array_equal(g, c)
+
+
+def test_live_loop_follows_main_ts(W):
+    """renderFrame of src/main.ts:119-181: world.update every `update_interval` frames at t = total / interval / 60, the
+    re-sync order BVH -> instance -> draw_commands -> (geometry, topology, lights) -> uniforms -> reset, then
+    compute(frameCount) + present with frameCount restarting at 1."""
+    class Bridge:
+        def __init__(self):
+            self.hasNewData = self.hasNewGeometry = True
+            self.updates = []
+            self.lightCount = 2
+            for k in ("tlas", "blas", "instances", "draw_commands", "vertices", "normals", "uvs", "mesh_topology", "lights", "cameraData"):
+                setattr(self, k, k)
+
+        def update(self, t):
+            self.updates.append(t)
+            self.hasNewData = self.hasNewGeometry = True
+
+        def updateCamera(self, w, h):
+            pass
+
+    rec, b = Recording(), Bridge()
+    loop = W.LiveLoop(rec, b, 64, 48, update_interval=3)
+    for _ in range(8):
+        loop.render_frame()
+    names = [c[0] for c in rec.calls]
+    first_sync = ["updateCombinedBVH", "updateBuffer", "updateBuffer", "updateCombinedGeometry", "updateBuffer", "updateBuffer",
+                  "updateSceneUniforms", "resetAccumulation"]
+    assert names[:8] == first_sync and names[8:10] == ["compute", "present"]
+    kinds = [c[1] for c in rec.calls[:8] if c[0] == "updateBuffer"]
+    assert kinds == ["instance", "draw_commands", "topology", "lights"]
+    assert [c[1] for c in rec.calls if c[0] == "compute"] == [1, 2, 3, 1, 2, 3, 1, 2]      # accumulation restarts after an update
+    assert b.updates == [3 / 3 / 60, 6 / 3 / 60]
+    assert names.count("resetAccumulation") == 3
+    # update_interval <= 0: the world is never advanced, one sync, frameCount keeps counting
+    rec2, b2 = Recording(), Bridge()
+    loop2 = W.LiveLoop(rec2, b2, 64, 48, update_interval=0)
+    for _ in range(4):
+        loop2.render_frame()
+    assert b2.updates == [] and [c[1] for c in rec2.calls if c[0] == "compute"] == [1, 2, 3, 4]

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""An animated, skinned glTF through the live loop (src/main.ts:119-181): per displayed frame the world advances
+(animation, skinning, BLAS + TLAS rebuild), the scene is re-uploaded, one 1-spp frame is traced and presented.
+Compares the scene compiler's CPU BLAS builder with the GPU builder hook.  usage: animate_bench.py [nu] [nv] [frames]"""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import webgpu_raytracer_amd as W  # noqa: E402
+import test_gltf  # noqa: E402
+
+nu = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+nv = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+glb, n_tris = test_gltf.big_skinned_glb(W, nu, nv)
+for use_gpu in (False, True):
+    r = W.WebGPURenderer(0)
+    r.buildPipeline(8, 1)
+    b = W.WorldBridge()
+    if use_gpu:
+        b.setBlasBuilder(r)
+    b.loadScene("viewer", glbData=glb)
+    W.upload_scene(r, b, 1920, 1080)
+    loop = W.LiveLoop(r, b, 1920, 1080, update_interval=1)
+    loop.render_frame()
+    r.sync()
+    t_upd = t_sync = t_trace = 0.0
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        b.update(loop.totalFrameCount / 60)
+        t1 = time.perf_counter()
+        W.sync_world(r, b, 1920, 1080)
+        t2 = time.perf_counter()
+        loop.frameCount = 1
+        loop.totalFrameCount += 1
+        r.compute(1)
+        r.present()
+        r.sync()
+        t3 = time.perf_counter()
+        t_upd += t1 - t0
+        t_sync += t2 - t1
+        t_trace += t3 - t2
+    f = frames / 1e3
+    print("%d triangles skinned + animated, 1920x1080, BLAS builder = %s: update(t) %.1f ms, re-upload %.1f ms, trace+present %.1f ms "
+          "-> %.1f frames/s" % (n_tris, "GPU (rt_build_blas)" if use_gpu else "CPU", t_upd / f, t_sync / f, t_trace / f,
+                                frames / (t_upd + t_sync + t_trace)))
+    r.destroy()

@@ -8,11 +8,11 @@ repo root) or through importlib.
 """
 from . import _build
 from .world_bridge import WorldBridge
-from .renderer import WebGPURenderer, RendererError, upload_scene
+from .renderer import WebGPURenderer, RendererError, upload_scene, sync_world, LiveLoop
 from .recorder import FrameLoop
 from . import textures
 
-__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "FrameLoop", "textures", "build"]
+__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "sync_world", "LiveLoop", "FrameLoop", "textures", "build"]
 
 
 def build(force=False):

@@ -315,3 +315,50 @@ def upload_scene(renderer, bridge, width, height):
     renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount)
     renderer.recreateBindGroup()
     renderer.resetAccumulation()
+
+
+def sync_world(renderer, bridge, width, height):
+    """The per-frame scene sync of the live loop (src/main.ts:133-163): when the bridge has new data, re-upload BVH,
+    instances, draw commands and — if the geometry changed — vertices, topology and lights; then camera uniforms,
+    rebind if a buffer grew, reset the accumulation.  Returns True when something was uploaded."""
+    if not bridge.hasNewData:
+        return False
+    rebind = False
+    rebind |= bool(renderer.updateCombinedBVH(bridge.tlas, bridge.blas))
+    rebind |= bool(renderer.updateBuffer("instance", bridge.instances))
+    rebind |= bool(renderer.updateBuffer("draw_commands", bridge.draw_commands))
+    if bridge.hasNewGeometry:
+        rebind |= bool(renderer.updateCombinedGeometry(bridge.vertices, bridge.normals, bridge.uvs))
+        rebind |= bool(renderer.updateBuffer("topology", bridge.mesh_topology))
+        rebind |= bool(renderer.updateBuffer("lights", bridge.lights))
+        bridge.hasNewGeometry = False
+    bridge.updateCamera(width, height)
+    renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount)
+    if rebind:
+        renderer.recreateBindGroup()
+    renderer.resetAccumulation()
+    bridge.hasNewData = False
+    return True
+
+
+class LiveLoop:
+    """`renderFrame` of src/main.ts:119-181 without the browser: every `update_interval` frames the world advances to
+    t = totalFrameCount / update_interval / 60 (animation + rebuild), the scene is re-synced, accumulation restarts;
+    every call traces one frame and presents."""
+
+    def __init__(self, renderer, bridge, width, height, update_interval=0):
+        self.renderer, self.bridge = renderer, bridge
+        self.width, self.height = width, height
+        self.update_interval = int(update_interval)      # <= 0: the world is never advanced (main.ts:127)
+        self.frameCount = 0
+        self.totalFrameCount = 0
+
+    def render_frame(self):
+        if self.update_interval > 0 and self.frameCount >= self.update_interval:
+            self.bridge.update(self.totalFrameCount / (self.update_interval or 1) / 60)
+        if sync_world(self.renderer, self.bridge, self.width, self.height):
+            self.frameCount = 0
+        self.frameCount += 1
+        self.totalFrameCount += 1
+        self.renderer.compute(self.frameCount)
+        self.renderer.present()
