@@ -192,7 +192,7 @@ def main():
                        "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
                        "parallelism": "16-row stripes x %d ranks + 1 RCCL reduce/image" % world if world > 1 else "1 GPU",
                        "frames_per_dispatch": args.batch, "rays_per_image": int(rays_total / args.steps)},
-            "roofline": {"bound": "hbm", "kernel": "k_pathtrace", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_pathtrace_persistent", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "avg_launch_ms": round(ktime["pathtrace_ms"], 4),
                          "avg_primary_ms": round(ktime["primary_ms"], 4), "launches": ktime["launches"],
