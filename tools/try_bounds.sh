@@ -3,7 +3,7 @@
 for w in 3 4 5 6; do
 python - <<PY
 import re, webgpu_raytracer_amd as W
-p="webgpu-raytracer_amd/csrc/kernels.hip.h"
+p="webgpu-raytracer_amd/csrc/k_pathtrace.hip.h"
 s=open(p).read()
 s2=re.sub(r"__launch_bounds__\(256, \d+\) void k_pathtrace_persistent","__launch_bounds__(256, $w) void k_pathtrace_persistent",s)
 open(p,"w").write(s2)

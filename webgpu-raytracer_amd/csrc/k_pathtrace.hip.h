@@ -1,0 +1,850 @@
+// k_pathtrace.hip.h — k_pathtrace (one pixel per lane), the wave-level traverse() with its LDS triangle queue, shade_bounce() and k_pathtrace_persistent.
+// Part of the kernel set of csrc/kernels.hip.h (included from there, in order; not a stand-alone header).
+#ifndef MI355RT_K_PATHTRACE_HIP_H
+#define MI355RT_K_PATHTRACE_HIP_H
+
+namespace rtk {
+
+// ======================================================================= path tracer
+// One sample: Raytracer.wgsl ray_color (:607-783).
+template <bool DETAIL>
+__device__ rt3 ray_color(const DevScene& S, const DevFrame& F, const rt_scene_uniforms& U, rt3 ro, rt3 rd,
+                         uint32_t& rng, uint32_t p_idx, LaneCounters& c) {
+  rt3 throughput = rt3_splat(1.0f);
+  rt3 radiance = rt3_splat(0.0f);
+  float prev_bsdf_pdf = 0.0f;
+  bool specular_bounce = true;
+
+  // depth 0 comes from the G-buffer
+  if (F.depth[p_idx] >= 1.0f) return radiance;
+  float4 g = F.normal_id[p_idx];
+  uint32_t tri = rt_f2u(g.z);
+  uint32_t inst = rt_f2u(g.w);
+  InvRows m = load_inv_rows(S, inst);
+  Bary b = barycentrics(S, tri, mul_point(m, ro), mul_dir(m, rd));
+  float hit_t = b.t;
+  float4 tidx = S.topo[5 * tri];
+  float2 uv0 = S.uv[rt_f2u(tidx.x)], uv1 = S.uv[rt_f2u(tidx.y)], uv2 = S.uv[rt_f2u(tidx.z)];
+  rt2 tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+  rt3 normal = unpack_normal(g.x, g.y);
+  uint32_t ga = F.albedo[p_idx];
+  rt3 albedo = rt3_make(rt_from_unorm8(ga & 255u), rt_from_unorm8((ga >> 8) & 255u), rt_from_unorm8((ga >> 16) & 255u));
+  rt3 world_geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+
+  for (uint32_t depth = 0u; depth < F.max_depth; depth++) {
+    if (DETAIL) c.shaded++;
+    float4 d0 = S.topo[5 * tri + 1], d1 = S.topo[5 * tri + 2], d2 = S.topo[5 * tri + 3], d3 = S.topo[5 * tri + 4];
+    uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
+    rt3 hit_p = ro + rd * hit_t;
+
+    normal = (rt_dot(rd, normal) < 0.0f) ? normal : -normal;
+    world_geom_n = (rt_dot(rd, world_geom_n) < 0.0f) ? world_geom_n : -world_geom_n;
+
+    float metallic = d1.x, roughness = d1.y;
+    if (d2.y > -0.5f) {
+      rt3 mr = sample_tex(S, tex_uv, rt_f2i32_sat(d2.y));
+      metallic *= mr.z;
+      roughness *= mr.y;
+    }
+    roughness = rt_max(roughness, 0.005f);
+    rt3 emissive = xyz(d3);
+    if (d2.w > -0.5f) emissive = emissive * sample_tex(S, tex_uv, rt_f2i32_sat(d2.w));
+    rt3 f0 = rt_mix3(rt3_splat(0.04f), albedo, metallic);
+
+    // emissive / light
+    if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
+      rt3 em_val = (mat_type == 3u) ? albedo : emissive;
+      if (specular_bounce) {
+        radiance = radiance + throughput * em_val;
+      } else {
+        radiance = radiance +
+                   throughput * em_val * power_heuristic(prev_bsdf_pdf, light_pdf(S, U.light_count, tri, inst, hit_t, rd));
+      }
+      if (mat_type == 3u) break;
+    }
+
+    // next-event estimation
+    if (mat_type != 2u) {
+      LightSample ls = sample_light(S, U.light_count, hit_p, rng);
+      if (ls.pdf > 0.0f) {
+        c.shadow++;
+        if (!trace_any<DETAIL>(S, U.blas_base_idx, hit_p + world_geom_n * 1e-4f, ls.dir, RT_T_MIN, ls.dist - 2e-4f, c)) {
+          rt3 bsdf_val = rt3_splat(0.0f);
+          float bsdf_pdf = 0.0f;
+          if (mat_type == 0u) {
+            bsdf_val = albedo / RT_PI;
+            bsdf_pdf = rt_max(rt_dot(normal, ls.dir), 0.0f) / RT_PI;
+          } else if (mat_type == 1u) {
+            bsdf_val = eval_ggx(normal, -rd, ls.dir, roughness, f0);
+            rt3 H = rt_normalize(-rd + ls.dir);
+            bsdf_pdf = (ggx_d(rt_dot(normal, H), roughness * roughness) * rt_max(rt_dot(normal, H), 0.0f)) /
+                       (4.0f * rt_max(rt_dot(-rd, H), 0.0f));
+          }
+          if (bsdf_pdf > 0.0f) {
+            radiance = radiance + throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                                      rt_max(rt_dot(normal, ls.dir), 0.0f) / ls.pdf;
+          }
+        }
+      }
+    }
+
+    Scatter sc;
+    if (mat_type == 0u) {
+      sc = sample_diffuse(normal, albedo, rng);
+    } else if (mat_type == 1u) {
+      sc = sample_ggx(normal, -rd, roughness, f0, rng);
+    } else {
+      sc = sample_dielectric(rd, normal, d1.z, albedo, rng);
+    }
+    if (mat_type != 2u && rt_dot(sc.dir, world_geom_n) <= 0.0f) {
+      sc.pdf = 0.0f;
+      sc.throughput = rt3_splat(0.0f);
+    }
+    if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) break;
+
+    throughput = throughput * sc.throughput;
+    rt3 offset_n = (rt_dot(sc.dir, world_geom_n) > 0.0f) ? world_geom_n : -world_geom_n;
+    ro = hit_p + offset_n * 1e-4f;
+    rd = sc.dir;
+    prev_bsdf_pdf = sc.pdf;
+    specular_bounce = sc.specular;
+
+    if (depth > 3u) {  // Russian roulette
+      float p = rt_max(throughput.x, rt_max(throughput.y, throughput.z));
+      if (rand_pcg(rng) > p) break;
+      throughput = throughput / p;
+    }
+
+    if (depth < F.max_depth - 1u) {
+      c.extension++;
+      Hit hit = trace_closest<DETAIL>(S, U.blas_base_idx, ro, rd, RT_T_MIN, RT_T_MAX, c);
+      if (hit.inst < 0) break;
+      hit_t = hit.t;
+      tri = (uint32_t)hit.tri;
+      inst = (uint32_t)hit.inst;
+      m = load_inv_rows(S, inst);
+      b = barycentrics(S, tri, mul_point(m, ro), mul_dir(m, rd));
+      tidx = S.topo[5 * tri];
+      uint32_t i0 = rt_f2u(tidx.x), i1 = rt_f2u(tidx.y), i2 = rt_f2u(tidx.z);
+      uv0 = S.uv[i0];
+      uv1 = S.uv[i1];
+      uv2 = S.uv[i2];
+      tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+      rt3 ln = rt_normalize(xyz(S.nrm[i0]) * b.w + xyz(S.nrm[i1]) * b.u + xyz(S.nrm[i2]) * b.v);
+      normal = rt_normalize(normal_to_world(m, ln));
+      float4 nd0 = S.topo[5 * tri + 1], nd2 = S.topo[5 * tri + 3];
+      albedo = xyz(nd0);
+      if (nd2.x > -0.5f) albedo = albedo * sample_tex(S, tex_uv, rt_f2i32_sat(nd2.x));
+      if (nd2.z > -0.5f) {
+        rt3 n_map = sample_tex(S, tex_uv, rt_f2i32_sat(nd2.z)) * 2.0f - rt3_splat(1.0f);
+        rt3 T = rt_normalize(b.e1);
+        rt3 B = rt_normalize(rt_cross(ln, T));
+        rt3 ln_mapped = rt_normalize(T * n_map.x + B * n_map.y + ln * n_map.z);
+        normal = rt_normalize(normal_to_world(m, ln_mapped));
+      }
+      world_geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+    }
+  }
+  return radiance;
+}
+
+// Raytracer.wgsl `main` (:791-819)
+template <bool DETAIL>
+__global__ __launch_bounds__(64) void k_pathtrace(DevScene S, DevFrame F, rt_scene_uniforms U) {
+  uint32_t x, y;
+  bool live = tile_pixel(U, x, y) && owns_row(F, y);
+  LaneCounters c = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    const uint32_t p_idx = y * U.width + x;
+    rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+    rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+    rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+    rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+    const float lens = U.camera.origin[3];
+    rt3 col = rt3_splat(0.0f);
+    for (uint32_t i = 0u; i < F.spp; i++) {
+      uint32_t rng = init_rng(p_idx, U.frame_count * F.spp + i);
+      rt3 off = rt3_splat(0.0f);
+      if (lens > 0.0f) {  // random_in_unit_disk (:201-205)
+        float r = rt_sqrt(rand_pcg(rng));
+        float theta = RT_TWO_PI * rand_pcg(rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+      rt3 d = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      col = col + ray_color<DETAIL>(S, F, U, cam_o + off, d, rng, p_idx, c);
+    }
+    col = col / (float)F.spp;
+    float4 acc = make_float4(col.x, col.y, col.z, 1.0f);
+    if (U.frame_count > 1u) {
+      float4 prev = F.accum[p_idx];
+      acc = make_float4(prev.x + col.x, prev.y + col.y, prev.z + col.z, prev.w + 1.0f);
+    }
+    F.accum[p_idx] = acc;
+  }
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x);
+}
+
+// ============================================================ path tracer, persistent form
+// k_pathtrace_persistent: the production path-trace kernel.
+//
+//  * persistent waves: the grid is sized to the resident wave count; each wave pulls 8x8 pixel
+//    tiles from a global ticket counter until the image is exhausted (one ray per lane);
+//  * path regeneration: a lane whose path ended (light hit, miss, absorbed, Russian roulette,
+//    depth limit) takes the next pixel of its wave's current tile, found with a ballot/mbcnt prefix
+//    over the idle mask, so the 64 lanes stay busy instead of waiting for the longest path;
+//  * per trip every live lane executes exactly one bounce: shade -> (NEE shadow ray) -> scatter ->
+//    (extension ray), so the wave runs the two traversals and the shading code converged;
+//  * traversal data (nodes, triangle records, instance records) is staged once per workgroup in LDS
+//    when it fits (LDS = true); larger scenes read the same records through L1/L2;
+//  * TLAS and BLAS are walked by ONE loop with an in-instance flag, so lanes in different
+//    instances / levels share the node fetch + slab test.
+// Per-path arithmetic and RNG draw order are exactly those of ray_color above (and of the oracle);
+// only the scheduling differs, which cannot change any pixel because paths are independent.
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct TravMem {  // pointers may be LDS or global; the template flag keeps the two code paths apart
+  const f4* nodes;
+  const f4* tri_geom;
+  const f4* inst_trav;
+};
+
+__device__ __forceinline__ bool hit_box4(f4 lo, f4 hi, const LocalRay& r, float t_min, float t_max) {
+  float t1x = lo.x * r.inv_d.x - r.o_inv_d.x, t2x = hi.x * r.inv_d.x - r.o_inv_d.x;
+  float t1y = lo.y * r.inv_d.y - r.o_inv_d.y, t2y = hi.y * r.inv_d.y - r.o_inv_d.y;
+  float t1z = lo.z * r.inv_d.z - r.o_inv_d.z, t2z = hi.z * r.inv_d.z - r.o_inv_d.z;
+  float nx = rt_min(t1x, t2x), ny = rt_min(t1y, t2y), nz = rt_min(t1z, t2z);
+  float fx = rt_max(t1x, t2x), fy = rt_max(t1y, t2y), fz = rt_max(t1z, t2z);
+  float tm_near = rt_max(t_min, rt_max(nx, rt_max(ny, nz)));
+  float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
+  return tm_near <= tm_far;
+}
+__device__ __forceinline__ LocalRay to_instance(const TravMem& M, uint32_t inst, rt3 o, rt3 d, uint32_t& blas_off) {
+  f4 r0 = M.inst_trav[4 * inst + 0], r1 = M.inst_trav[4 * inst + 1], r2 = M.inst_trav[4 * inst + 2];
+  blas_off = rt_f2u(M.inst_trav[4 * inst + 3].x);
+  rt3 lo = rt3_make(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w * 1.0f, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w * 1.0f,
+                    r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w * 1.0f);
+  rt3 ld = rt3_make(r0.x * d.x + r0.y * d.y + r0.z * d.z + r0.w * 0.0f, r1.x * d.x + r1.y * d.y + r1.z * d.z + r1.w * 0.0f,
+                    r2.x * d.x + r2.y * d.y + r2.z * d.z + r2.w * 0.0f);
+  return make_ray(lo, ld);
+}
+
+// Branch-free Möller–Trumbore: same operations and the same accept/reject truth table as
+// hit_triangle_raw (Raytracer.wgsl:443-453), evaluated without early exits so that a wave testing
+// 64 different triangles stays converged.
+__device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max, float& t_out) {
+  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
+  rt3 h = rt_cross(r.d, e2);
+  float a = rt_dot(e1, h);
+  float f = 1.0f / a;
+  rt3 s = r.o - v0;
+  float u = f * rt_dot(s, h);
+  rt3 q = rt_cross(s, e1);
+  float v = f * rt_dot(r.d, q);
+  float t = f * rt_dot(e2, q);
+  t_out = t;
+  bool reject = (rt_abs(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+  return !reject & (t > t_min) & (t < t_max);
+}
+
+// ---------------------------------------------------------------------------------------------
+// traverse(): one walk over TLAS and BLAS nodes for the 64 rays of a wave.
+//
+// Divergence control.  A lane is SEARCHING (walking nodes: slab tests, instance entry/exit) or
+// WAITING (it reached a BLAS leaf whose box it hits and has queued that leaf's triangles).  Every
+// trip of the loop lets all searching lanes take ONE node step.  When enough triangle tests are queued
+// (RT_FLUSH_ITEMS) or nobody is searching any more, the wave flushes the queue:
+//   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
+//     3-bit leaf counts, each owner also posts its instance-space ray;
+//   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
+//     with 6 triangles no longer holds 63 other lanes hostage;
+//   * each owner then folds its own results in leaf order with the reference's strict `t < closest`
+//     rule and goes back to searching.
+// Equivalence with the reference's sequential leaf loop (Raytracer.wgsl:474-482): a test is accepted
+// there iff geometry passes, t > t_min and t < the running closest; the running closest never exceeds
+// the closest at leaf entry, so testing every triangle against the leaf-entry bound in parallel and
+// re-applying `t < running closest` in order during the fold makes exactly the same decisions.
+// Per lane the sequence of visited nodes, tested triangles and tie-breaks is the reference's.
+// ANY = shadow ray (first accepted hit ends the ray), else closest hit.
+struct WaveWork {
+  f4* rays;         // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
+  uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
+};
+#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 6
+#endif
+#ifndef RT_FLUSH_ITEMS
+#define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
+                            // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
+#endif
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
+                                         rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
+                                         int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
+  const uint32_t lane = threadIdx.x & 63u;
+  float closest = t_max;
+  int32_t best_tri = -1, best_inst = -1;
+  bool any = false;
+  bool searching = active && blas_base != 0u;
+  bool waiting = false;
+  uint32_t leaf = 0u;
+  LocalRay r = make_ray(o, d);
+  const uint32_t tlas_end = rt_f2u(M.nodes[0].w);
+  uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
+  uint32_t cur_inst = 0u;
+  bool in_blas = false;
+  for (;;) {
+#ifdef RT_WAVE_STATS
+    {
+      const bool any_search = __ballot(searching) != 0ull;
+      if (COUNT && lane == 0u && any_search) n_nodes++;  // wave-level node steps
+    }
+#endif
+    // ---- range exhausted (rare): leave the instance, or finish
+    if (searching && curr >= end) {
+      if (in_blas && tlas_next < tlas_end) {
+        in_blas = false;  // back to the world-space ray and the TLAS cursor
+        r = make_ray(o, d);
+        curr = tlas_next;
+        end = tlas_end;
+        base = 0u;
+      } else {
+        searching = false;
+      }
+    }
+    // ---- one node step for every searching lane (curr < end holds); select-based, two branches only
+    if (searching) {
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+#ifndef RT_WAVE_STATS
+      if (COUNT) n_nodes++;
+#endif
+      const bool hit = hit_box4(lo, hi, r, t_min, closest);
+      const uint32_t data = rt_f2u(hi.w);
+      const bool leafhit = hit && data != 0u;
+      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
+      const bool got_leaf = leafhit && in_blas;
+      if (leafhit && !in_blas) {  // TLAS leaf: enter the instance
+        cur_inst = data >> 3;
+        uint32_t off;
+        r = to_instance(M, cur_inst, o, d, off);
+        tlas_next = next;
+        base = blas_base + off;
+        end = base + rt_f2u(M.nodes[2 * base].w);
+        next = base;
+        in_blas = true;
+      }
+      leaf = got_leaf ? data : leaf;
+      waiting = got_leaf;
+      searching = !got_leaf;
+      curr = next;
+    }
+    // ---- flush the triangle queue?
+    const unsigned long long smask = __ballot(searching);
+    const unsigned long long wmask = __ballot(waiting);
+    if ((smask | wmask) == 0ull) break;
+    const uint32_t cnt = waiting ? (leaf & 7u) : 0u;
+    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                           4u * (uint32_t)__builtin_popcountll(b2);
+    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
+      const uint32_t excl =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+      const uint32_t first = leaf >> 3;
+      if (waiting) {
+        f4 ra, rb;
+        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = t_min;
+        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
+        W.rays[2 * lane] = ra;
+        W.rays[2 * lane + 1] = rb;
+        const uint32_t tag = lane << 26;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++)
+          if (i < cnt) W.items[excl + i] = tag | (first + i);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = 0; c < total; c += 64u) {
+#ifdef RT_WAVE_STATS
+        if (COUNT && lane == 0u) n_tris++;  // wave-level 64-item chunks
+#endif
+        const uint32_t j = c + lane;
+        if (j < total) {
+          const uint32_t it = W.items[j];
+          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
+          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
+          LocalRay q;
+          q.o = rt3_make(ra.x, ra.y, ra.z);
+          q.d = rt3_make(rb.x, rb.y, rb.z);
+          float t;
+          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
+          W.items[j] = rt_f2u(ok ? t : -1.0f);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (waiting) {
+        // fold this lane's results in leaf order (strict t < closest: the first of equal hits wins)
+        bool stop = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++) {
+          if (i < cnt && !stop) {
+#ifndef RT_WAVE_STATS
+            if (COUNT) n_tris++;
+#endif
+            const float t = rt_u2f(W.items[excl + i]);
+            if (t > 0.0f && t < closest) {
+              if (ANY) {
+                any = true;
+                stop = true;
+              } else {
+                closest = t;
+                best_tri = (int32_t)(first + i);
+                best_inst = (int32_t)cur_inst;
+              }
+            }
+          }
+        }
+        waiting = false;
+        searching = !(ANY && any);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  out_t = closest;
+  out_tri = best_tri;
+  out_inst = best_inst;
+  out_any = any;
+}
+
+struct PathState {
+  uint32_t pixel, rng, depth, sample;
+  rt3 ro, rd, throughput, radiance, col;
+  float prev_pdf;
+  bool specular;
+  // current surface
+  float hit_t;
+  uint32_t tri, inst;
+  rt3 normal, geom_n, albedo;
+  rt2 tex_uv;
+};
+
+// surface frame of the hit (tri, inst) for the ray (ro, rd): Raytracer.wgsl:738-779
+__device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, bool from_gbuffer, float gx, float gy,
+                                              uint32_t galbedo) {
+  InvRows m = load_inv_rows(S, p.inst);
+  Bary b = barycentrics(S, p.tri, mul_point(m, p.ro), mul_dir(m, p.rd));
+  float4 tidx = S.topo[5 * p.tri];
+  uint32_t i0 = rt_f2u(tidx.x), i1 = rt_f2u(tidx.y), i2 = rt_f2u(tidx.z);
+  float2 uv0 = S.uv[i0], uv1 = S.uv[i1], uv2 = S.uv[i2];
+  p.tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+  if (from_gbuffer) {
+    p.hit_t = b.t;
+    p.normal = unpack_normal(gx, gy);
+    p.albedo = rt3_make(rt_from_unorm8(galbedo & 255u), rt_from_unorm8((galbedo >> 8) & 255u),
+                        rt_from_unorm8((galbedo >> 16) & 255u));
+  } else {
+    rt3 ln = rt_normalize(xyz(S.nrm[i0]) * b.w + xyz(S.nrm[i1]) * b.u + xyz(S.nrm[i2]) * b.v);
+    p.normal = rt_normalize(normal_to_world(m, ln));
+    float4 nd0 = S.topo[5 * p.tri + 1], nd2 = S.topo[5 * p.tri + 3];
+    p.albedo = xyz(nd0);
+    if (nd2.x > -0.5f) p.albedo = p.albedo * sample_tex(S, p.tex_uv, rt_f2i32_sat(nd2.x));
+    if (nd2.z > -0.5f) {
+      rt3 n_map = sample_tex(S, p.tex_uv, rt_f2i32_sat(nd2.z)) * 2.0f - rt3_splat(1.0f);
+      rt3 T = rt_normalize(b.e1);
+      rt3 B = rt_normalize(rt_cross(ln, T));
+      rt3 ln_mapped = rt_normalize(T * n_map.x + B * n_map.y + ln * n_map.z);
+      p.normal = rt_normalize(normal_to_world(m, ln_mapped));
+    }
+  }
+  p.geom_n = rt_normalize(normal_to_world(m, rt_normalize(rt_cross(b.e1, b.e2))));
+}
+
+// One bounce of ray_color for a path whose surface frame is ready (Raytracer.wgsl:656-728): emissive / MIS, the
+// three NEE draws and the pending NEE term, BSDF sampling, throughput, ray offset, Russian roulette, depth limit.
+// The shadow ray and the extension ray it asks for are traced by the caller (megakernel trip or wavefront stage).
+struct BounceOut {
+  bool want_shadow, want_extend, nee_valid, ended;
+  rt3 sh_o, sh_d, nee;
+  float sh_tmax;
+};
+__device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_count, uint32_t max_depth, PathState& p,
+                                             BounceOut& o) {
+  o.want_shadow = o.want_extend = o.nee_valid = false;
+  o.sh_o = o.sh_d = o.nee = rt3_splat(0.0f);
+  o.sh_tmax = 0.0f;
+  float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
+  const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
+  const rt3 hit_p = p.ro + p.rd * p.hit_t;
+  p.normal = (rt_dot(p.rd, p.normal) < 0.0f) ? p.normal : -p.normal;
+  p.geom_n = (rt_dot(p.rd, p.geom_n) < 0.0f) ? p.geom_n : -p.geom_n;
+  float metallic = d1.x, roughness = d1.y;
+  if (d2.y > -0.5f) {
+    rt3 mr = sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.y));
+    metallic *= mr.z;
+    roughness *= mr.y;
+  }
+  roughness = rt_max(roughness, 0.005f);
+  rt3 emissive = xyz(d3);
+  if (d2.w > -0.5f) emissive = emissive * sample_tex(S, p.tex_uv, rt_f2i32_sat(d2.w));
+  const rt3 f0 = rt_mix3(rt3_splat(0.04f), p.albedo, metallic);
+
+  bool ended = false;
+  if (mat_type == 3u || rt_length(emissive) > 1e-4f) {
+    rt3 em_val = (mat_type == 3u) ? p.albedo : emissive;
+    if (p.specular) {
+      p.radiance = p.radiance + p.throughput * em_val;
+    } else {
+      p.radiance = p.radiance + p.throughput * em_val *
+                                    power_heuristic(p.prev_pdf, light_pdf(S, light_count, p.tri, p.inst, p.hit_t, p.rd));
+    }
+    if (mat_type == 3u) ended = true;
+  }
+  if (!ended) {
+    if (mat_type != 2u) {  // NEE: the 3 draws happen here, the shadow ray is traced below
+      LightSample ls = sample_light(S, light_count, hit_p, p.rng);
+      if (ls.pdf > 0.0f) {
+        rt3 bsdf_val = rt3_splat(0.0f);
+        float bsdf_pdf = 0.0f;
+        if (mat_type == 0u) {
+          bsdf_val = p.albedo / RT_PI;
+          bsdf_pdf = rt_max(rt_dot(p.normal, ls.dir), 0.0f) / RT_PI;
+        } else if (mat_type == 1u) {
+          bsdf_val = eval_ggx(p.normal, -p.rd, ls.dir, roughness, f0);
+          rt3 H = rt_normalize(-p.rd + ls.dir);
+          bsdf_pdf = (ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f)) /
+                     (4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
+        }
+        o.want_shadow = true;  // the reference traces the shadow ray before looking at bsdf_pdf
+        o.sh_o = hit_p + p.geom_n * 1e-4f;
+        o.sh_d = ls.dir;
+        o.sh_tmax = ls.dist - 2e-4f;
+        o.nee_valid = bsdf_pdf > 0.0f;
+        if (o.nee_valid) {
+          o.nee = p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                rt_max(rt_dot(p.normal, ls.dir), 0.0f) / ls.pdf;
+        }
+      }
+    }
+    Scatter sc;
+    if (mat_type == 0u) {
+      sc = sample_diffuse(p.normal, p.albedo, p.rng);
+    } else if (mat_type == 1u) {
+      sc = sample_ggx(p.normal, -p.rd, roughness, f0, p.rng);
+    } else {
+      sc = sample_dielectric(p.rd, p.normal, d1.z, p.albedo, p.rng);
+    }
+    if (mat_type != 2u && rt_dot(sc.dir, p.geom_n) <= 0.0f) {
+      sc.pdf = 0.0f;
+      sc.throughput = rt3_splat(0.0f);
+    }
+    if (sc.pdf <= 0.0f || rt_length(sc.throughput) <= 0.0f) {
+      ended = true;
+    } else {
+      p.throughput = p.throughput * sc.throughput;
+      rt3 offset_n = (rt_dot(sc.dir, p.geom_n) > 0.0f) ? p.geom_n : -p.geom_n;
+      p.ro = hit_p + offset_n * 1e-4f;
+      p.rd = sc.dir;
+      p.prev_pdf = sc.pdf;
+      p.specular = sc.specular;
+      if (p.depth > 3u) {
+        float pr = rt_max(p.throughput.x, rt_max(p.throughput.y, p.throughput.z));
+        if (rand_pcg(p.rng) > pr) {
+          ended = true;
+        } else {
+          p.throughput = p.throughput / pr;
+        }
+      }
+      if (!ended) {
+        if (p.depth < max_depth - 1u) {
+          o.want_extend = true;
+        } else {
+          ended = true;  // depth limit: the loop condition ends the path after this bounce
+        }
+      }
+    }
+  }
+  o.ended = ended;
+}
+
+// number of 16-byte LDS slots the whole scene needs (traversal records + shading arrays)
+__host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
+                                                  uint32_t n_lights) {
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)2 * n_verts +
+         ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
+}
+
+// Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
+// is latency bound and gains ~11 % from 6 waves/SIMD even with the spills that costs (measured on MI355X).
+template <bool DETAIL, bool LDS>
+__global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
+                                                              uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
+                                                              uint32_t n_tris_total, uint32_t n_inst_total,
+                                                              uint32_t n_verts_total,
+                                                              const DevFrameSlot* __restrict__ slots, uint32_t n_slots) {
+  // Batched dispatch (rt_compute_batch): the launch covers n_slots consecutive compute() frames. The work item is
+  // one (frame, pixel): tickets enumerate (frame, tile) pairs, so a launch has n_slots times as many tickets and the
+  // persistent waves stay fed and balanced even when a rank owns 1/8 of the image. With n_slots > 1 every item
+  // writes its frame colour to F.frame_col and k_accumulate_frames adds the frames in frame order afterwards, which
+  // makes the result bit-identical to n_slots separate dispatches; with n_slots == 1 the item accumulates directly.
+  extern __shared__ f4 s_scene[];
+  // per-wave triangle work queue at the start of LDS, staged scene after it
+  WaveWork WW;
+  {
+    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+    WW.rays = reinterpret_cast<f4*>(wbase);
+    WW.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  }
+  f4* const s_records = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
+  TravMem M;
+  DevScene S = Sg;
+  if (LDS) {
+    // Small scene: the whole scene (traversal records AND the arrays shading reads) lives in LDS,
+    // staged once per workgroup; only textures, the G-buffer and the accumulation buffer stay in HBM.
+    f4* dst = s_records;
+    auto stage = [&](const void* src, size_t slots) {
+      const f4* g = reinterpret_cast<const f4*>(src);
+      f4* base = dst;
+      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
+      dst += slots;
+      return base;
+    };
+    f4* ln = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    f4* lt = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    f4* li = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    S.topo = reinterpret_cast<const float4*>(stage(Sg.topo, (size_t)5 * n_tris_total));
+    S.pos = reinterpret_cast<const float4*>(stage(Sg.pos, n_verts_total));
+    S.nrm = reinterpret_cast<const float4*>(stage(Sg.nrm, n_verts_total));
+    // uv (8 B/vertex) and lights (8 B each): the device buffers are allocated with >= 16-byte slack
+    S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));
+    S.inst = reinterpret_cast<const float4*>(stage(Sg.inst, (size_t)9 * n_inst_total));
+    S.lights = reinterpret_cast<const uint2*>(stage(Sg.lights, ((size_t)Sg.n_lights + 1) / 2));
+    S.light_rec = reinterpret_cast<const float4*>(stage(Sg.light_rec, (size_t)4 * Sg.n_lights));
+    __syncthreads();
+    M.nodes = ln;
+    M.tri_geom = lt;
+    M.inst_trav = li;
+    S.nodes = reinterpret_cast<const float4*>(ln);
+    S.tri_geom = reinterpret_cast<const float4*>(lt);
+    S.inst_trav = reinterpret_cast<const float4*>(li);
+  } else {
+    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
+    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
+    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
+  }
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tiles_x = (U.width + 7u) / 8u;
+  // tickets enumerate only the tile rows this rank owns when the stripes are tile-aligned
+  const uint32_t n_tiles = tiles_x * (F.own_period ? F.own_tile_rows : (U.height + 7u) / 8u);
+  const rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+  const rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+  const rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+  const rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+  const float lens = U.camera.origin[3];
+
+  // wave-uniform work cursor: pixels [tile_pos, 64) of tile `tile` are still unassigned
+  uint32_t tile = 0xffffffffu, tile_pos = 64u;
+  bool work_left = true;
+
+  PathState p;
+  uint32_t item_slot = 0u;  // frame of the batch the lane's current (frame, pixel) item belongs to
+  bool alive = false;       // lane owns a running path
+  bool have_pixel = false;  // lane owns a pixel whose samples are not all done
+  uint32_t cnt_ext = 0, cnt_shadow = 0, cnt_nodes = 0, cnt_tris = 0, cnt_shaded = 0;
+  p.pixel = 0; p.rng = 0; p.depth = 0; p.sample = 0; p.prev_pdf = 0.0f; p.specular = true; p.hit_t = 0.0f;
+  p.tri = 0; p.inst = 0;
+  p.ro = p.rd = p.throughput = p.radiance = p.col = p.normal = p.geom_n = p.albedo = rt3_splat(0.0f);
+  p.tex_uv = rt2_make(0.0f, 0.0f);
+
+  for (;;) {
+    // ------------------------------------------------------------ regenerate
+    // (a) wave-wide: every lane without a pixel takes the next unassigned one of the wave's tile.
+    //     All lanes execute this loop (busy lanes with need = false) so that the wave-uniform cursor
+    //     (tile, tile_pos, work_left) stays identical in every lane.
+    {
+      bool need = !alive && !have_pixel;
+      for (;;) {
+        const unsigned long long mask = __ballot(need);
+        if (mask == 0ull || !work_left) break;
+        if (tile_pos >= 64u) {
+          const int leader = __builtin_ctzll(mask);
+          uint32_t t = 0;
+          if (lane == (uint32_t)leader) t = atomicAdd(ticket, 1u);
+          t = __shfl(t, leader, 64);
+          if (t >= n_tiles * n_slots) {
+            work_left = false;
+            break;
+          }
+          tile = t;  // frame-major ticket: frame = t / n_tiles, tile = t % n_tiles
+          tile_pos = 0u;
+        }
+        // rank of this lane among the needy lanes
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const uint32_t slot = tile_pos + rank;
+        if (need && slot < 64u) {
+          const uint32_t tile_in_frame = tile % n_tiles;
+          uint32_t trow = tile_in_frame / tiles_x;
+          if (F.own_period) trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
+          const uint32_t x = (tile_in_frame % tiles_x) * 8u + (slot & 7u);
+          const uint32_t y = trow * 8u + (slot >> 3);
+          need = false;
+          if (x < U.width && y < U.height && owns_row(F, y)) {
+            have_pixel = true;
+            p.pixel = y * U.width + x;
+            p.sample = 0u;
+            item_slot = tile / n_tiles;
+            p.col = rt3_splat(0.0f);
+          }
+        }
+        tile_pos += (uint32_t)__builtin_popcountll(mask);
+      }
+    }
+    // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
+    if (!alive && have_pixel) {
+      const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
+      const DevFrameSlot slot = slots[item_slot];
+      p.rng = init_rng(p.pixel, slot.frame_count * F.spp + p.sample);
+      rt3 off = rt3_splat(0.0f);
+      if (lens > 0.0f) {
+        float r = rt_sqrt(rand_pcg(p.rng));
+        float theta = RT_TWO_PI * rand_pcg(p.rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      float u = ((float)x + 0.5f + slot.jitter_x * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + slot.jitter_y * (float)U.height) / (float)U.height;
+      p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      p.ro = cam_o + off;
+      p.throughput = rt3_splat(1.0f);
+      p.radiance = rt3_splat(0.0f);
+      p.prev_pdf = 0.0f;
+      p.specular = true;
+      p.depth = 0u;
+      // background pixel (or MAX_DEPTH = 0): the sample is black and ends at once
+      if (!(slot.depth[p.pixel] >= 1.0f) && F.max_depth != 0u) {
+        float4 g = slot.normal_id[p.pixel];
+        p.tri = rt_f2u(g.z);
+        p.inst = rt_f2u(g.w);
+        setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+        alive = true;
+      }
+    }
+    const bool running = alive;
+    bool path_done = have_pixel && !alive;  // background sample ends immediately
+
+    // ------------------------------------------------------------ shade one bounce
+    bool want_shadow = false, want_extend = false;
+    bool nee_valid = false;
+    rt3 sh_o = rt3_splat(0.0f), sh_d = rt3_splat(0.0f), nee = rt3_splat(0.0f);
+    float sh_tmax = 0.0f;
+#ifdef RT_WAVE_STATS
+    if (DETAIL && lane == 0u) cnt_shaded++;  // wave-level outer trips
+#endif
+    if (running) {
+#ifndef RT_WAVE_STATS
+      if (DETAIL) cnt_shaded++;
+#endif
+      BounceOut bo;
+      shade_bounce(S, U.light_count, F.max_depth, p, bo);
+      want_shadow = bo.want_shadow;
+      want_extend = bo.want_extend;
+      nee_valid = bo.nee_valid;
+      sh_o = bo.sh_o;
+      sh_d = bo.sh_d;
+      sh_tmax = bo.sh_tmax;
+      nee = bo.nee;
+      const bool ended = bo.ended;
+      if (ended) path_done = true;
+    }
+
+#ifdef RT_EXP_NOSHADOW
+    want_shadow = false;  // timing experiment only
+#endif
+#ifdef RT_EXP_NOEXT
+    if (want_extend) { want_extend = false; path_done = true; }  // timing experiment only
+#endif
+    // ------------------------------------------------------------ shadow rays (any hit)
+    if (__ballot(want_shadow) != 0ull) {
+      float t_;
+      int32_t a_, b_;
+      bool occluded;
+      traverse<true, DETAIL>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
+                             cnt_nodes, cnt_tris);
+      if (want_shadow) {
+        cnt_shadow++;
+        if (!occluded && nee_valid) p.radiance = p.radiance + nee;  // nothing is added when bsdf_pdf <= 0
+      }
+    }
+
+    // ------------------------------------------------------------ extension rays (closest hit)
+    if (__ballot(want_extend) != 0ull) {
+      float t_;
+      int32_t tri_, inst_;
+      bool any_;
+      traverse<false, DETAIL>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
+                              cnt_nodes, cnt_tris);
+      if (want_extend) {
+        cnt_ext++;
+        if (inst_ < 0) {
+          path_done = true;
+        } else {
+          p.hit_t = t_;
+          p.tri = (uint32_t)tri_;
+          p.inst = (uint32_t)inst_;
+          setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+          p.depth++;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------ sample / pixel finished
+    if (path_done) {
+      alive = false;
+      p.col = p.col + p.radiance;
+      p.sample++;
+      if (p.sample >= F.spp) {  // the item's last sample: Raytracer.wgsl:811-818
+        rt3 c = p.col / (float)F.spp;
+        if (F.frame_col) {
+          // batched: park the frame colour; k_accumulate_frames adds the frames in order
+          F.frame_col[(size_t)item_slot * ((size_t)U.width * U.height) + p.pixel] = make_float4(c.x, c.y, c.z, 1.0f);
+        } else {
+          float4 acc = make_float4(c.x, c.y, c.z, 1.0f);
+          if (slots[0].frame_count > 1u) {
+            float4 prev = F.accum[p.pixel];
+            acc = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
+          }
+          F.accum[p.pixel] = acc;
+        }
+        have_pixel = false;
+      }
+    }
+    if (!work_left && __ballot(alive || have_pixel) == 0ull) break;
+  }
+
+  // counters: one flush per persistent wave
+  LaneCounters c;
+  c.primary = 0;
+  c.extension = cnt_ext;
+  c.shadow = cnt_shadow;
+  c.nodes = cnt_nodes;
+  c.tris = cnt_tris;
+  c.shaded = cnt_shaded;
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
+}  // namespace rtk
+#endif

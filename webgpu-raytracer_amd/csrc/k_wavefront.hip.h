@@ -1,0 +1,466 @@
+// k_wavefront.hip.h — wavefront form: k_wf_shade / k_wf_trace over device queues, k_accumulate_frames.
+// Part of the kernel set of csrc/kernels.hip.h (included from there, in order; not a stand-alone header).
+#ifndef MI355RT_K_WAVEFRONT_HIP_H
+#define MI355RT_K_WAVEFRONT_HIP_H
+
+namespace rtk {
+
+// ================================================================== path tracer, wavefront form
+// For scenes whose traversal records do not fit LDS (hundreds of thousands of triangles, a thousand instances) a ray
+// visits 70+ nodes with a long tail, and the per-trip lockstep of the persistent kernel leaves 60 % of the lanes idle
+// while they wait on L2 / Infinity-Cache latency.  The wavefront form splits a bounce into stages with the path state in
+// HBM (84 B per path, 288 GB to spare):
+//   k_wf_shade   one lane per live path: surface frame + shade_bounce(); appends the shadow ray and the extension ray
+//                to device queues (wave-aggregated atomics), finishes paths that end
+//   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result and pulls the
+//                next ray from the queue (batched, >= RT_WF_REFILL lanes), so the slowest ray no longer holds 63 lanes;
+//                same node step / LDS triangle queue as traverse()
+// Stages of one depth run as separate launches in stream order; the host enqueues all depths without reading anything
+// back (queue sizes stay on the device).  Per path the arithmetic, RNG order and f32 addition order are unchanged, so
+// the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
+// Restriction: SPP == 1 (the reference's default); other SPP values use the persistent kernel.
+#define RT_WF_REFILL 16
+
+// Device queues are filled and drained in chunks of RT_WF_CHUNK entries: a wave reserves a chunk with ONE atomic
+// and then appends with ballot/mbcnt ranks (a queue counter is a single address: ~88 atomics/us chip-wide, so one atomic
+// per wave-append or per 16-ray pull caps a stage at a few Grays/s). Unused tail entries of a chunk hold RT_WF_INVALID.
+#define RT_WF_CHUNK 256u
+#define RT_WF_INVALID 0xffffffffu
+struct WaveQueueWriter {
+  uint32_t pos, end;  // wave-uniform cursor into the current chunk
+};
+// returns the slot for lanes with want == true (RT_WF_INVALID otherwise); call from wave-uniform control flow
+__device__ __forceinline__ uint32_t wq_append(WaveQueueWriter& w, uint32_t* counter, uint32_t* ids, bool want) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return RT_WF_INVALID;
+  const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+  if (w.pos + n > w.end) {
+    for (uint32_t i = w.pos + lane; i < w.end; i += 64u) ids[i] = RT_WF_INVALID;
+    uint32_t b = 0;
+    if (lane == 0u) b = atomicAdd(counter, RT_WF_CHUNK);
+    b = __shfl(b, 0, 64);
+    w.pos = b;
+    w.end = b + RT_WF_CHUNK;
+  }
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  const uint32_t slot = w.pos + rank;
+  w.pos += n;
+  return want ? slot : RT_WF_INVALID;
+}
+__device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* ids) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i = w.pos + lane; i < w.end; i += 64u) ids[i] = RT_WF_INVALID;
+}
+
+__device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
+                                              rt3 nee) {
+  W.a[id] = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
+  W.b[id] = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
+  W.c[id] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
+  W.d[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
+  W.e[id] = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
+}
+
+template <bool FIRST, bool DETAIL>
+__global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_scene_uniforms U, WfState W, WfQueues Q,
+                                                  const DevFrameSlot* __restrict__ slots, uint32_t n_slots,
+                                                  uint32_t depth) {
+  const uint32_t npx = U.width * U.height;
+  uint32_t* cnt = Q.counters + 8u * depth;
+  const uint32_t count = FIRST ? npx * n_slots : cnt[0];
+  const uint32_t* active_in = Q.active[depth & 1u];
+  uint32_t cnt_shaded = 0;
+  WaveQueueWriter wq_shadow = {0u, 0u}, wq_ext = {0u, 0u};
+  // wave-uniform loop (every lane of a wave takes part in the queue appends)
+  for (uint32_t base_idx = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base_idx < count; base_idx += gridDim.x * 256u) {
+    const uint32_t idx = base_idx + (threadIdx.x & 63u);
+    bool live = idx < count;
+    uint32_t id = 0u;
+    if (live) {
+      id = FIRST ? idx : active_in[idx];
+      live = id != RT_WF_INVALID;
+    }
+    BounceOut bo;
+    bo.want_shadow = bo.want_extend = bo.nee_valid = bo.ended = false;
+    bo.sh_o = bo.sh_d = bo.nee = rt3_splat(0.0f);
+    bo.sh_tmax = 0.0f;
+    PathState p;
+    p.col = rt3_splat(0.0f);
+    p.sample = 0u;
+    p.pixel = id % npx;
+    p.tri = p.inst = p.depth = p.rng = 0u;
+    p.hit_t = p.prev_pdf = 0.0f;
+    p.specular = true;
+    p.ro = p.rd = p.throughput = p.radiance = p.normal = p.geom_n = p.albedo = rt3_splat(0.0f);
+    p.tex_uv = rt2_make(0.0f, 0.0f);
+    if (live) {
+    if (FIRST) {
+      const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
+      if (!owns_row(F, y)) live = false;
+      const DevFrameSlot slot = slots[id / npx];
+      p.rng = init_rng(p.pixel, slot.frame_count);  // SPP == 1: frame_count * SPP + 0
+      rt3 cam_o = rt3_make(U.camera.origin[0], U.camera.origin[1], U.camera.origin[2]);
+      rt3 off = rt3_splat(0.0f);
+      const float lens = U.camera.origin[3];
+      if (lens > 0.0f) {
+        float r = rt_sqrt(rand_pcg(p.rng));
+        float theta = RT_TWO_PI * rand_pcg(p.rng);
+        float st, ct;
+        rt_sincos(theta, &st, &ct);
+        rt3 rdk = lens * rt3_make(r * ct, r * st, 0.0f);
+        rt3 cu = rt3_make(U.camera.u[0], U.camera.u[1], U.camera.u[2]);
+        rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
+        off = cu * rdk.x + cv * rdk.y;
+      }
+      rt3 cam_ll = rt3_make(U.camera.lower_left[0], U.camera.lower_left[1], U.camera.lower_left[2]);
+      rt3 cam_h = rt3_make(U.camera.horizontal[0], U.camera.horizontal[1], U.camera.horizontal[2]);
+      rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
+      float u = ((float)x + 0.5f + slot.jitter_x * (float)U.width) / (float)U.width;
+      float v = 1.0f - ((float)y + 0.5f + slot.jitter_y * (float)U.height) / (float)U.height;
+      p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
+      p.ro = cam_o + off;
+      p.throughput = rt3_splat(1.0f);
+      p.radiance = rt3_splat(0.0f);
+      p.prev_pdf = 0.0f;
+      p.specular = true;
+      p.depth = 0u;
+      if (live && (slot.depth[p.pixel] >= 1.0f || F.max_depth == 0u)) {  // background (or MAX_DEPTH = 0): black sample
+        F.frame_col[id] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        live = false;
+      }
+      if (live) {
+        float4 g = slot.normal_id[p.pixel];
+        p.tri = rt_f2u(g.z);
+        p.inst = rt_f2u(g.w);
+        setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+      }
+    } else {
+      const float4 a = W.a[id], b = W.b[id], c = W.c[id], d = W.d[id], e = W.e[id];
+      p.ro = xyz(a);
+      p.hit_t = a.w;
+      p.rd = xyz(b);
+      p.prev_pdf = b.w;
+      p.throughput = xyz(c);
+      p.rng = rt_f2u(c.w);
+      p.radiance = xyz(d);
+      const uint32_t fl = rt_f2u(d.w);
+      p.depth = fl & 0xffu;
+      p.specular = (fl & WF_FLAG_SPECULAR) != 0u;
+      p.tri = rt_f2u(e.w);
+      p.inst = W.inst[id];
+      setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+    }
+    if (live) {
+      if (DETAIL) cnt_shaded++;
+      shade_bounce(S, U.light_count, F.max_depth, p, bo);
+    }
+    }  // if (live) — everything below runs for the whole wave
+    const uint32_t sslot = wq_append(wq_shadow, &cnt[1], Q.shadow_ids, live && bo.want_shadow);
+    if (sslot != RT_WF_INVALID) {
+      Q.shadow_ids[sslot] = id;
+      Q.shadow_rays[2 * sslot] = make_float4(bo.sh_o.x, bo.sh_o.y, bo.sh_o.z, bo.sh_tmax);
+      Q.shadow_rays[2 * sslot + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
+    }
+    const uint32_t eslot = wq_append(wq_ext, &cnt[2], Q.ext_ids, live && bo.want_extend);
+    if (eslot != RT_WF_INVALID) Q.ext_ids[eslot] = id;
+    if (live) {
+      if (bo.ended && !bo.want_shadow) {
+        F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
+      } else {
+        const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
+                               (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
+        wf_store_path(W, id, p, flags, bo.nee);
+      }
+    }
+  }
+  wq_finish(wq_shadow, Q.shadow_ids);
+  wq_finish(wq_ext, Q.ext_ids);
+  if (DETAIL) {
+    LaneCounters c = {0, 0, 0, 0, 0, cnt_shaded};
+    flush_counters<true>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+  }
+}
+
+// Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
+// else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
+template <bool ANY, bool DETAIL, bool LDS>
+__global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
+                                                            WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
+                                                            uint32_t n_tris_total, uint32_t n_inst_total) {
+  extern __shared__ f4 s_scene[];
+  WaveWork W;
+  {
+    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+    W.rays = reinterpret_cast<f4*>(wbase);
+    W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  }
+  TravMem M;
+  if (LDS) {
+    f4* dst = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
+    auto stage = [&](const void* src, size_t slots) {
+      const f4* g = reinterpret_cast<const f4*>(src);
+      f4* base = dst;
+      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
+      dst += slots;
+      return base;
+    };
+    M.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    M.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    M.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    __syncthreads();
+  } else {
+    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
+    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
+    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t blas_base = U.blas_base_idx;
+  uint32_t* cnt = Q.counters + 8u * depth;
+  const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
+  uint32_t* head = ANY ? &cnt[3] : &cnt[4];
+  uint32_t* next_active = Q.active[(depth + 1u) & 1u];
+  uint32_t* next_count = Q.counters + 8u * (depth + 1u);
+  const uint32_t tlas_end = blas_base ? rt_f2u(M.nodes[0].w) : 0u;
+
+  // per-lane ray + traversal state
+  bool have_ray = false, searching = false, waiting = false, in_blas = false, any = false;
+  uint32_t id = 0u, leaf = 0u, curr = 0u, end = 0u, base = 0u, tlas_next = 0u, cur_inst = 0u;
+  rt3 o = rt3_splat(0.0f), d = rt3_splat(0.0f);
+  float t_max = 0.0f, closest = 0.0f;
+  int32_t best_tri = -1, best_inst = -1;
+  LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
+  bool queue_left = true;
+  uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
+  WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
+  uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
+
+  for (;;) {
+    // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
+    const bool done = have_ray && !searching && !waiting;
+    const bool idle = !have_ray || done;
+    const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
+    const unsigned long long busy_m = __ballot(searching || waiting);
+    if (idle_m != 0ull &&
+        ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
+         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+      bool push_next = false;
+      if (done) {
+        if (ANY) {
+          float4 dd = Ws.d[id];
+          const uint32_t fl = rt_f2u(dd.w);
+          if (!any && (fl & WF_FLAG_NEE_VALID) != 0u) {
+            const float4 e = Ws.e[id];
+            dd.x = dd.x + e.x;  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
+            dd.y = dd.y + e.y;
+            dd.z = dd.z + e.z;
+          }
+          if ((fl & WF_FLAG_ENDED) != 0u)
+            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
+          else
+            Ws.d[id] = dd;
+        } else {
+          if (best_inst < 0) {  // miss: the path ends with what it has
+            const float4 dd = Ws.d[id];
+            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
+          } else {
+            float4 a = Ws.a[id];
+            a.w = closest;
+            Ws.a[id] = a;
+            float4 e = Ws.e[id];
+            e.w = rt_u2f((uint32_t)best_tri);
+            Ws.e[id] = e;
+            Ws.inst[id] = (uint32_t)best_inst;
+            float4 dd = Ws.d[id];
+            const uint32_t fl = rt_f2u(dd.w);
+            dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
+            Ws.d[id] = dd;
+            push_next = true;
+          }
+        }
+        have_ray = false;
+      }
+      if (!ANY) {
+        const uint32_t slot = wq_append(wq_next, &next_count[0], next_active, push_next);
+        if (slot != RT_WF_INVALID) next_active[slot] = id;
+      }
+      // pull: needy lanes take consecutive entries of the wave's chunk; a new chunk costs one atomic
+      const bool need = !have_ray;
+      const unsigned long long need_m = __ballot(need);
+      if (queue_left && need_m != 0ull) {
+        if (chunk_pos >= chunk_end) {
+          uint32_t bq = 0;
+          if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+          bq = __shfl(bq, 0, 64);
+          if (bq >= n_rays) {
+            queue_left = false;
+          } else {
+            chunk_pos = bq;
+            chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
+          }
+        }
+        if (queue_left) {
+          const uint32_t rank =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+          const uint32_t qi = chunk_pos + rank;
+          chunk_pos += (uint32_t)__builtin_popcountll(need_m);
+          if (need && qi < chunk_end) {
+            const uint32_t rid = ANY ? Q.shadow_ids[qi] : Q.ext_ids[qi];
+            if (rid != RT_WF_INVALID) {
+              id = rid;
+              if (ANY) {
+                const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
+                o = xyz(r0);
+                d = xyz(r1);
+                t_max = r0.w;
+              } else {
+                o = xyz(Ws.a[id]);
+                d = xyz(Ws.b[id]);
+                t_max = RT_T_MAX;
+              }
+              n_traced++;
+              have_ray = true;
+              closest = t_max;
+              best_tri = -1;
+              best_inst = -1;
+              any = false;
+              r = make_ray(o, d);
+              curr = 0u;
+              end = tlas_end;
+              base = 0u;
+              in_blas = false;
+              searching = blas_base != 0u;
+              waiting = false;
+            }
+          }
+        }
+      }
+    }
+    if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+
+    // ---- range exhausted: leave the instance, or finish the ray
+    if (searching && curr >= end) {
+      if (in_blas && tlas_next < tlas_end) {
+        in_blas = false;
+        r = make_ray(o, d);
+        curr = tlas_next;
+        end = tlas_end;
+        base = 0u;
+      } else {
+        searching = false;
+      }
+    }
+    // ---- one node step
+    if (searching) {
+      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
+      if (DETAIL) n_nodes++;
+      const bool hit = hit_box4(lo, hi, r, RT_T_MIN, closest);
+      const uint32_t data = rt_f2u(hi.w);
+      const bool leafhit = hit && data != 0u;
+      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
+      const bool got_leaf = leafhit && in_blas;
+      if (leafhit && !in_blas) {
+        cur_inst = data >> 3;
+        uint32_t off;
+        r = to_instance(M, cur_inst, o, d, off);
+        tlas_next = next;
+        base = blas_base + off;
+        end = base + rt_f2u(M.nodes[2 * base].w);
+        next = base;
+        in_blas = true;
+      }
+      leaf = got_leaf ? data : leaf;
+      waiting = got_leaf;
+      searching = !got_leaf;
+      curr = next;
+    }
+    // ---- flush the triangle queue?
+    const unsigned long long smask = __ballot(searching);
+    const unsigned long long wmask = __ballot(waiting);
+    const uint32_t cntl = waiting ? (leaf & 7u) : 0u;
+    const unsigned long long b0 = __ballot((cntl & 1u) != 0u), b1 = __ballot((cntl & 2u) != 0u), b2 = __ballot((cntl & 4u) != 0u);
+    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                           4u * (uint32_t)__builtin_popcountll(b2);
+    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
+      const uint32_t excl =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+      const uint32_t first = leaf >> 3;
+      if (waiting) {
+        f4 ra, rb;
+        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = RT_T_MIN;
+        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
+        W.rays[2 * lane] = ra;
+        W.rays[2 * lane + 1] = rb;
+        const uint32_t tag = lane << 26;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++)
+          if (i < cntl) W.items[excl + i] = tag | (first + i);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = 0; c < total; c += 64u) {
+        const uint32_t j = c + lane;
+        if (j < total) {
+          const uint32_t it = W.items[j];
+          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
+          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
+          LocalRay q;
+          q.o = rt3_make(ra.x, ra.y, ra.z);
+          q.d = rt3_make(rb.x, rb.y, rb.z);
+          float t;
+          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
+          W.items[j] = rt_f2u(ok ? t : -1.0f);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (waiting) {
+        bool stop = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; i++) {
+          if (i < cntl && !stop) {
+            if (DETAIL) n_tris++;
+            const float t = rt_u2f(W.items[excl + i]);
+            if (t > 0.0f && t < closest) {
+              if (ANY) {
+                any = true;
+                stop = true;
+              } else {
+                closest = t;
+                best_tri = (int32_t)(first + i);
+                best_inst = (int32_t)cur_inst;
+              }
+            }
+          }
+        }
+        waiting = false;
+        searching = !stop;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (!ANY) wq_finish(wq_next, next_active);
+  LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
+// Ordered accumulation of a batched dispatch: acc = (frame_count > 1 ? acc : 0) + (col_f, 1) for f = 0..n-1, the
+// exact sequence of f32 additions n separate dispatches perform (Raytracer.wgsl:813-818).
+__global__ __launch_bounds__(256) void k_accumulate_frames(DevFrame F, const DevFrameSlot* __restrict__ slots,
+                                                           uint32_t n_slots, uint32_t width, uint32_t height) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t npx = width * height;
+  if (p >= npx || !owns_row(F, p / width)) return;
+  float4 acc = F.accum[p];
+  for (uint32_t f = 0; f < n_slots; f++) {
+    const float4 c = F.frame_col[(size_t)f * npx + p];
+    if (slots[f].frame_count > 1u)
+      acc = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, acc.w + 1.0f);
+    else
+      acc = make_float4(c.x, c.y, c.z, 1.0f);
+  }
+  F.accum[p] = acc;
+}
+
+}  // namespace rtk
+#endif
