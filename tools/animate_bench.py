@@ -19,7 +19,7 @@ glb, n_tris = test_gltf.big_skinned_glb(W, nu, nv)
 for use_gpu in (False, True):
     r = W.WebGPURenderer(0)
     r.buildPipeline(8, 1)
-    b = W.WorldBridge()
+    b = W.WorldBridge(zero_copy=True)
     if use_gpu:
         b.setBlasBuilder(r)
     b.loadScene("viewer", glbData=glb)

@@ -855,7 +855,7 @@ struct BuildNode {
 };
 class BlasBuilder {
  public:
-  BlasBuilder(const std::vector<float>& verts4, const std::vector<uint32_t>& indices) : indices_(indices) {
+  BlasBuilder(const float* verts4, size_t /*n_verts*/, const std::vector<uint32_t>& indices) : indices_(indices) {
     size_t n = indices.size() / 3;
     boxes_.reserve(n);
     centers_.reserve(n);
@@ -1065,6 +1065,8 @@ struct ms_world {
   // glTF scene graph (SceneData.nodes / skins / animations) and World.active_anim_index
   GltfScene gltf;
   size_t active_anim = 0;
+  std::vector<float> scratch_nodes;     // BLAS build output of the geometry being processed (world_update)
+  std::vector<uint32_t> scratch_order;
   // optional BLAS builder hook (ms_world_set_blas_builder): the GPU builder of libmi355rt.so
   ms_blas_builder blas_hook = nullptr;
   void* blas_hook_user = nullptr;
@@ -1163,8 +1165,15 @@ static void world_update(ms_world& w, float time = 0.0f) {
       w.blas_root_offsets.push_back(0);
       continue;
     }
-    std::vector<float> v4, n4, uv2;
-    v4.reserve(geo.positions.size() * 4);
+    // vertices / normals / uvs of this geometry are written in place at the end of the world arrays
+    const size_t n_geo_verts = geo.positions.size();
+    const uint32_t v_offset = (uint32_t)(w.vertices.size() / 4);
+    w.vertices.resize(w.vertices.size() + n_geo_verts * 4);
+    w.normals.resize(w.normals.size() + n_geo_verts * 4);
+    w.uvs.resize(w.uvs.size() + n_geo_verts * 2);
+    float* v4 = &w.vertices[(size_t)v_offset * 4];
+    float* n4 = &w.normals[(size_t)v_offset * 4];
+    float* uv2 = &w.uvs[(size_t)v_offset * 2];
     // rebuilder.rs:36-91: linear blend skinning with joint matrices global(joint) * inverse_bind
     const GSkin* skin = (geo.skin_index >= 0 && (size_t)geo.skin_index < w.gltf.skins.size()) ? &w.gltf.skins[(size_t)geo.skin_index] : nullptr;
     std::vector<M4> joint_mats;
@@ -1193,40 +1202,40 @@ static void world_update(ms_world& w, float time = 0.0f) {
       }
       if (is_nan(p)) p = v3(0, 0, 0);
       if (is_nan(n)) n = v3(0, 0, 1);
-      const float pv[4] = {p.x, p.y, p.z, 1.0f}, nv[4] = {n.x, n.y, n.z, 0.0f};
-      v4.insert(v4.end(), pv, pv + 4);
-      n4.insert(n4.end(), nv, nv + 4);
-      uv2.push_back(uv.x);
-      uv2.push_back(uv.y);
+      v4[i * 4] = p.x; v4[i * 4 + 1] = p.y; v4[i * 4 + 2] = p.z; v4[i * 4 + 3] = 1.0f;
+      n4[i * 4] = n.x; n4[i * 4 + 1] = n.y; n4[i * 4 + 2] = n.z; n4[i * 4 + 3] = 0.0f;
+      uv2[i * 2] = uv.x;
+      uv2[i * 2 + 1] = uv.y;
     }
     // BLAS: nodes (8 f32 each, BLAS-local skips) + triangle order, from the CPU builder or from the hook
-    std::vector<float> packed;
-    std::vector<uint32_t> order;
+    std::vector<float>& packed = w.scratch_nodes;  // reused between updates: no 17 MB of zero-fill per frame
+    std::vector<uint32_t>& order = w.scratch_order;
     const uint32_t n_tris = (uint32_t)(geo.indices.size() / 3);
+    size_t n_packed = 0;                            // nodes in `packed`
     bool built = false;
     if (w.blas_hook && n_tris) {
-      packed.resize((size_t)2 * n_tris * 8);
-      order.resize(n_tris);
+      if (packed.size() < (size_t)2 * n_tris * 8) packed.resize((size_t)2 * n_tris * 8);
+      if (order.size() < n_tris) order.resize(n_tris);
       uint32_t n_nodes = 0;
-      const int rc = w.blas_hook(w.blas_hook_user, v4.data(), (uint32_t)(v4.size() / 4), geo.indices.data(), n_tris, packed.data(),
+      const int rc = w.blas_hook(w.blas_hook_user, v4, (uint32_t)n_geo_verts, geo.indices.data(), n_tris, packed.data(),
                                  2 * n_tris, &n_nodes, order.data());
       if (rc >= 0) {
-        packed.resize((size_t)n_nodes * 8);
+        n_packed = n_nodes;
         built = true;
       } else {
         g_last_error = "BLAS builder hook failed (" + std::to_string(rc) + "); the CPU builder was used for this update";
       }
     }
     if (!built) {
-      BlasBuilder bb(v4, geo.indices);
+      BlasBuilder bb(v4, n_geo_verts, geo.indices);
       bb.build();
       packed.clear();
       pack_nodes(bb.nodes, packed);
+      n_packed = bb.nodes.size();
       order.assign(bb.order.begin(), bb.order.end());
     }
-    uint32_t v_offset = (uint32_t)(w.vertices.size() / 4);
     uint32_t topo_start = (uint32_t)(w.topology.size() / 20);
-    for (size_t ni = 0; ni < packed.size() / 8; ni++) {  // leaf `first` becomes a global topology index (rebuilder.rs:123-134)
+    for (size_t ni = 0; ni < n_packed; ni++) {  // leaf `first` becomes a global topology index (rebuilder.rs:123-134)
       uint32_t data;
       std::memcpy(&data, &packed[ni * 8 + 7], 4);
       if (data != 0) {
@@ -1234,24 +1243,21 @@ static void world_update(ms_world& w, float time = 0.0f) {
         std::memcpy(&packed[ni * 8 + 7], &data, 4);
       }
     }
-    for (size_t i = 0; i < order.size(); i++) {
+    w.topology.resize(w.topology.size() + (size_t)n_tris * 20);
+    for (size_t i = 0; i < n_tris; i++) {
       size_t old_id = order[i];
-      uint32_t row[20];
+      uint32_t* row = &w.topology[((size_t)topo_start + i) * 20];
       row[0] = geo.indices[old_id * 3] + v_offset;
       row[1] = geo.indices[old_id * 3 + 1] + v_offset;
       row[2] = geo.indices[old_id * 3 + 2] + v_offset;
       row[3] = (uint32_t)gi;
       std::memcpy(&row[4], &geo.attributes[old_id * 16], 64);
-      w.topology.insert(w.topology.end(), row, row + 20);
       float mat_val = geo.attributes[old_id * 16 + 3];
       if (std::fabs(mat_val - 3.0f) < 1e-6f) emissive[gi].push_back(topo_start + (uint32_t)i);
     }
-    w.vertices.insert(w.vertices.end(), v4.begin(), v4.end());
-    w.normals.insert(w.normals.end(), n4.begin(), n4.end());
-    w.uvs.insert(w.uvs.end(), uv2.begin(), uv2.end());
-    w.blas.insert(w.blas.end(), packed.begin(), packed.end());
+    w.blas.insert(w.blas.end(), packed.begin(), packed.begin() + (long)n_packed * 8);
     w.blas_root_offsets.push_back(node_offset);
-    node_offset += (uint32_t)(packed.size() / 8);
+    node_offset += (uint32_t)n_packed;
     geom_ranges[gi] = {topo_start, (uint32_t)(w.topology.size() / 20) - topo_start};
   }
 

@@ -65,7 +65,10 @@ def _load():
 class WorldBridge:
     """Same data accessors as the reference class (world-bridge.ts:172-205)."""
 
-    def __init__(self):
+    def __init__(self, zero_copy=False):
+        """zero_copy=True hands out views into the scene compiler's arrays instead of copies — what the reference's
+        getters do with wasm memory (world-bridge.ts:172-205): valid until the next update() / loadScene() / close()."""
+        self._zero_copy = bool(zero_copy)
         self._lib = _load()
         self._world = None
         self._cache = {}
@@ -145,7 +148,7 @@ class WorldBridge:
         p = getattr(self._lib, "ms_world_" + name)(self._world, ctypes.byref(n))
         if n.value == 0:
             return np.zeros(0, dtype=dtype)
-        return np.ctypeslib.as_array(p, shape=(n.value,)).astype(dtype, copy=True)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).astype(dtype, copy=not self._zero_copy)
 
     def _refresh(self):
         for name in ("vertices", "normals", "uvs", "tlas", "blas", "instances", "camera"):
