@@ -48,6 +48,7 @@ struct Build {
   uint32_t* order_final; // leaves park their range here
   uint32_t* scratch_l;   // positions of misplaced elements, by rank
   uint32_t* scratch_r;
+  uint8_t* bin_cache;    // bin of the triangle at each position, written by the bin pass of the level
   BNode* nodes;
   uint32_t* counters;    // [0] next node id
 };
@@ -119,7 +120,7 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_wave, uint
 
 // blas.rs:149-177 + 201-217 for one node from its bins: best split, left count, child order
 __device__ __forceinline__ void sah_split(const uint32_t* bin_cnt, const uint32_t (*bin_box)[6], uint32_t count, int& leaf, int& split,
-                                          uint32_t& L, int& rotate) {
+                                          uint32_t& L, int& rotate, float* lbox, float* rbox) {
   float l_area[kBins], r_area[kBins];
   uint32_t l_cnt[kBins], r_cnt[kBins];
   const float inf = __uint_as_float(0x7f800000u);
@@ -165,6 +166,17 @@ __device__ __forceinline__ void sah_split(const uint32_t* bin_cnt, const uint32_
     if (L == 0u || L == count) leaf = 1;
     const float l_cost = l_area[best_split] * (float)L, r_cost = r_area[best_split + 1] * (float)(count - L);
     rotate = r_cost > l_cost;  // the costlier child goes first
+    // the children's boxes are the partial unions of the sweep: a child holds exactly the triangles of bins <= split
+    // (resp. > split), and min / max on the key order do not depend on the order of the operands
+    for (int c = 0; c < 3; c++) { lbox[c] = inf; lbox[c + 3] = -inf; rbox[c] = inf; rbox[c + 3] = -inf; }
+    for (int i = 0; i < kBins; i++) {
+      if (!bin_cnt[i]) continue;
+      float* bx = i <= best_split ? lbox : rbox;
+      for (int c = 0; c < 3; c++) {
+        bx[c] = tmin(bx[c], float_of(bin_box[i][c]));
+        bx[c + 3] = tmax(bx[c + 3], float_of(bin_box[i][c + 3]));
+      }
+    }
   }
   split = best_split;
 }
@@ -179,15 +191,16 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
   __shared__ uint32_t s_bin_box[kBins][6];
   __shared__ uint32_t s_wave[T / 64];
   __shared__ float s_f[2];        // split_min, scale
+  __shared__ float s_box[2][6];   // boxes of the left / right part
   __shared__ int32_t s_i[6];      // leaf flag, axis, best split, L, rotate, nbad
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= n_active) return;
   const uint32_t id = ids ? ids[blockIdx.x] : id0 + blockIdx.x;  // the BFS ids of a level are contiguous
   const uint32_t first = B.nodes[id].first, count = B.nodes[id].count, end = first + count;
 
-  // ---- 1. box of the range
+  // ---- 1. box of the range: the root reduces its triangles' boxes, every other node got its box from its parent's sweep
   uint32_t k[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  for (uint32_t p = first + tid; p < end; p += kThreads) {
+  for (uint32_t p = first + tid; id == 0u && p < end; p += kThreads) {
     const uint32_t t = B.order_in[p];
     const float4 a = B.tri_mn[t], b = B.tri_mx[t];
     k[0] = min(k[0], key_of(a.x)); k[1] = min(k[1], key_of(a.y)); k[2] = min(k[2], key_of(a.z));
@@ -209,10 +222,12 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
         kmn = min(kmn, s_red[w][c]);
         kmx = max(kmx, s_red[w][c + 3]);
       }
-      mn[c] = float_of(kmn);
-      mx[c] = float_of(kmx);
-      B.nodes[id].mn[c] = mn[c];
-      B.nodes[id].mx[c] = mx[c];
+      if (id == 0u) {
+        B.nodes[id].mn[c] = float_of(kmn);
+        B.nodes[id].mx[c] = float_of(kmx);
+      }
+      mn[c] = B.nodes[id].mn[c];
+      mx[c] = B.nodes[id].mx[c];
     }
     int leaf = count <= 4u;
     const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
@@ -239,6 +254,7 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
     for (uint32_t p = first + tid; p < end; p += kThreads) {
       const uint32_t t = B.order_in[p];
       const uint32_t b = bin_of(axis_of(B.tri_c[t], axis), split_min, scale);
+      B.bin_cache[p] = (uint8_t)b;
       const float4 a = B.tri_mn[t], c = B.tri_mx[t];
       atomicAdd(&s_bin_cnt[b], 1u);
       atomicMin(&s_bin_box[b][0], key_of(a.x)); atomicMin(&s_bin_box[b][1], key_of(a.y)); atomicMin(&s_bin_box[b][2], key_of(a.z));
@@ -249,7 +265,12 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
     if (tid == 0u) {
       int leaf, split, rotate;
       uint32_t L;
-      sah_split(s_bin_cnt, s_bin_box, count, leaf, split, L, rotate);
+      float lbox[6], rbox[6];
+      sah_split(s_bin_cnt, s_bin_box, count, leaf, split, L, rotate, lbox, rbox);
+      for (int c = 0; c < 6; c++) {
+        s_box[0][c] = lbox[c];
+        s_box[1][c] = rbox[c];
+      }
       s_i[0] = leaf;
       s_i[2] = split;
       s_i[3] = (int32_t)L;
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
   for (uint32_t base = 0; base < L; base += kThreads) {
     const uint32_t p = first + base + tid;
     bool bad = false;
-    if (base + tid < L) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) > split;
+    if (base + tid < L) bad = B.bin_cache[p] > split;
     uint32_t total;
     const uint32_t r = block_rank<T>(bad, s_wave, total);
     if (bad) B.scratch_l[first + run_l + r] = p;
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
   for (uint32_t base = 0; base < R; base += kThreads) {
     const uint32_t p = end - 1u - (base + tid);  // from the right end
     bool bad = false;
-    if (base + tid < R) bad = bin_of(axis_of(B.tri_c[B.order_in[p]], axis), split_min, scale) <= split;
+    if (base + tid < R) bad = B.bin_cache[p] <= split;
     uint32_t total;
     const uint32_t r = block_rank<T>(bad, s_wave, total);
     if (bad) B.scratch_r[first + run_r + r] = p;
@@ -309,6 +330,12 @@ __global__ __launch_bounds__(T) void k_level(Build B, const uint32_t* __restrict
     B.nodes[ids].count = l_count;
     B.nodes[ids + 1u].first = first + l_count;
     B.nodes[ids + 1u].count = count - l_count;
+    for (int c = 0; c < 3; c++) {  // after a rotation the former right part is the first child
+      B.nodes[ids].mn[c] = s_box[rotate ? 1 : 0][c];
+      B.nodes[ids].mx[c] = s_box[rotate ? 1 : 0][c + 3];
+      B.nodes[ids + 1u].mn[c] = s_box[rotate ? 0 : 1][c];
+      B.nodes[ids + 1u].mx[c] = s_box[rotate ? 0 : 1][c + 3];
+    }
     B.nodes[id].left = (int32_t)ids;
     B.nodes[id].right = (int32_t)(ids + 1u);
   }
@@ -330,6 +357,7 @@ struct BigNode {
   uint32_t box[6];
   uint32_t bin_cnt[kBins];
   uint32_t bin_box[kBins][6];
+  float lbox[6], rbox[6];  // boxes of the left / right part (from the sweep)
 };
 struct Chunk {
   uint32_t big, j;  // index into the level's BigNode array, chunk index inside the node
@@ -368,10 +396,12 @@ __global__ __launch_bounds__(64) void k_big_setup(Build B, BigNode* bn, uint32_t
   BigNode& N = bn[i];
   float mn[3], mx[3];
   for (int c = 0; c < 3; c++) {
-    mn[c] = float_of(N.box[c]);
-    mx[c] = float_of(N.box[c + 3]);
-    B.nodes[N.id].mn[c] = mn[c];
-    B.nodes[N.id].mx[c] = mx[c];
+    if (N.id == 0u) {  // only the root reduced its box (k_big_bounds); the others carry their parent's partial union
+      B.nodes[N.id].mn[c] = float_of(N.box[c]);
+      B.nodes[N.id].mx[c] = float_of(N.box[c + 3]);
+    }
+    mn[c] = B.nodes[N.id].mn[c];
+    mx[c] = B.nodes[N.id].mx[c];
   }
   const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
   const int axis = ey > ex ? 1 : ((ez > ex && ez > ey) ? 2 : 0);
@@ -402,6 +432,7 @@ __global__ __launch_bounds__(256) void k_big_bin(Build B, BigNode* bn, const Chu
   for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
     const uint32_t t = B.order_in[p];
     const uint32_t b = bin_of(axis_of(B.tri_c[t], axis), split_min, scale);
+    B.bin_cache[p] = (uint8_t)b;
     const float4 a = B.tri_mn[t], c = B.tri_mx[t];
     atomicAdd(&s_cnt[b], 1u);
     atomicMin(&s_box[b][0], key_of(a.x)); atomicMin(&s_box[b][1], key_of(a.y)); atomicMin(&s_box[b][2], key_of(a.z));
@@ -425,7 +456,7 @@ __global__ __launch_bounds__(64) void k_big_split(BigNode* bn, uint32_t n_big) {
   if (N.leaf) return;
   int leaf, split, rotate;
   uint32_t L;
-  sah_split(N.bin_cnt, N.bin_box, N.count, leaf, split, L, rotate);
+  sah_split(N.bin_cnt, N.bin_box, N.count, leaf, split, L, rotate, N.lbox, N.rbox);
   N.leaf = leaf;
   N.split = split;
   N.L = L;
@@ -444,7 +475,7 @@ __global__ __launch_bounds__(256) void k_big_count(Build B, const BigNode* __res
   const uint32_t lo = N.first + ch.j * kChunk, hi = min(lo + kChunk, N.first + N.count), mid = N.first + N.L;
   uint32_t cl = 0, cr = 0;
   for (uint32_t p = lo + threadIdx.x; p < hi; p += 256u) {
-    const bool right = bin_of(axis_of(B.tri_c[B.order_in[p]], N.axis), N.split_min, N.scale) > (uint32_t)N.split;
+    const bool right = B.bin_cache[p] > (uint32_t)N.split;
     cl += (p < mid && right) ? 1u : 0u;
     cr += (p >= mid && !right) ? 1u : 0u;
   }
@@ -494,7 +525,7 @@ __global__ __launch_bounds__(256) void k_big_scatter(Build B, const BigNode* __r
     const uint32_t p = q + threadIdx.x;
     bool bl = false, br = false;
     if (p < hi) {
-      const bool right = bin_of(axis_of(B.tri_c[B.order_in[p]], N.axis), N.split_min, N.scale) > (uint32_t)N.split;
+      const bool right = B.bin_cache[p] > (uint32_t)N.split;
       bl = p < mid && right;
       br = p >= mid && !right;
     }
@@ -548,6 +579,14 @@ __global__ __launch_bounds__(256) void k_big_copy(Build B, const BigNode* __rest
     B.nodes[ids].count = l_count;
     B.nodes[ids + 1u].first = N.first + l_count;
     B.nodes[ids + 1u].count = N.count - l_count;
+    const float* fb = rotate ? N.rbox : N.lbox;
+    const float* sb = rotate ? N.lbox : N.rbox;
+    for (int c = 0; c < 3; c++) {
+      B.nodes[ids].mn[c] = fb[c];
+      B.nodes[ids].mx[c] = fb[c + 3];
+      B.nodes[ids + 1u].mn[c] = sb[c];
+      B.nodes[ids + 1u].mx[c] = sb[c + 3];
+    }
     B.nodes[N.id].left = (int32_t)ids;
     B.nodes[N.id].right = (int32_t)(ids + 1u);
   }

@@ -46,6 +46,7 @@ struct rt_ctx {
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
   uint32_t bv_levels = 0;
+  void* bv_pinned = nullptr;  // 64 KB of pinned host memory for the per-level read-backs of rt_build_blas
   DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
@@ -329,6 +330,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
   }
+  if (c->bv_pinned) (void)hipHostFree(c->bv_pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -465,7 +467,7 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   int r;
   if ((r = ensure_buffer(c, c->bv_in, (size_t)n_verts * 16 + n * 12, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_order, n * 20, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_order, n * 21 + 16, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_active, n * 4, false)) < 0) return r;
   if ((r = ensure_buffer(c, c->bv_out, max_nodes * 32, false)) < 0) return r;
@@ -485,6 +487,7 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   B.order_final = ord + 2 * n;
   B.scratch_l = ord + 3 * n;
   B.scratch_r = ord + 4 * n;
+  B.bin_cache = (uint8_t*)(ord + 5 * n);
   B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
   B.counters = (uint32_t*)c->bv_counters.ptr;
   uint32_t* d_ids = (uint32_t*)c->bv_active.ptr;
@@ -500,7 +503,12 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   std::vector<std::pair<uint32_t, uint32_t>> levels;  // (first BFS id, node count) per level: the ids of a level are contiguous
   uint32_t n_active = 1, id0 = 0, total = 1;
   bool big_possible = n_tris > bvhb::kBig;
-  std::vector<bvhb::BNode> host_nodes;
+  int small_levels = 0;
+  if (!c->bv_pinned) HIP_TRY(c, hipHostMalloc(&c->bv_pinned, 1 << 16, hipHostMallocDefault));
+  uint32_t* pinned_counter = (uint32_t*)c->bv_pinned;
+  bvhb::BNode* pinned_nodes = (bvhb::BNode*)((char*)c->bv_pinned + 64);
+  const uint32_t pinned_node_cap = (uint32_t)(((1 << 16) - 64) / sizeof(bvhb::BNode));
+  std::vector<bvhb::BNode> host_nodes_vec;
   std::vector<bvhb::BigNode> big;
   std::vector<bvhb::Chunk> chunks;
   std::vector<uint32_t> small_ids;
@@ -512,8 +520,12 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
     small_ids.clear();
     if (big_possible) {
       // the few nodes of the first levels: those above kBig triangles are cut into chunks and worked on by many workgroups
-      host_nodes.resize(n_active);
-      HIP_TRY(c, hipMemcpyAsync(host_nodes.data(), B.nodes + id0, (size_t)n_active * sizeof(bvhb::BNode), hipMemcpyDeviceToHost, c->stream));
+      bvhb::BNode* host_nodes = pinned_nodes;
+      if (n_active > pinned_node_cap) {
+        host_nodes_vec.resize(n_active);
+        host_nodes = host_nodes_vec.data();
+      }
+      HIP_TRY(c, hipMemcpyAsync(host_nodes, B.nodes + id0, (size_t)n_active * sizeof(bvhb::BNode), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       for (uint32_t i = 0; i < n_active; i++) {
         if (host_nodes[i].count > bvhb::kBig) {
@@ -545,7 +557,8 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
       HIP_TRY(c, hipMemcpyAsync(d_big, big.data(), (size_t)nb * sizeof(bvhb::BigNode), hipMemcpyHostToDevice, c->stream));
       HIP_TRY(c, hipMemcpyAsync(d_chunks, chunks.data(), (size_t)nc * sizeof(bvhb::Chunk), hipMemcpyHostToDevice, c->stream));
       const dim3 gn((nb + 63) / 64), gc(nc);
-      hipLaunchKernelGGL(bvhb::k_big_bounds, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
+      if (id0 == 0)  // only the root reduces its box; children get theirs from the parent's sweep
+        hipLaunchKernelGGL(bvhb::k_big_bounds, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
       hipLaunchKernelGGL(bvhb::k_big_setup, gn, dim3(64), 0, c->stream, B, d_big, nb);
       hipLaunchKernelGGL(bvhb::k_big_bin, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
       hipLaunchKernelGGL(bvhb::k_big_split, gn, dim3(64), 0, c->stream, d_big, nb);
@@ -560,13 +573,17 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
         hipLaunchKernelGGL(bvhb::k_level<256>, dim3((uint32_t)small_ids.size()), dim3(256), 0, c->stream, B, (const uint32_t*)d_ids, 0u,
                            (uint32_t)small_ids.size());
       }
-    } else {
+    } else if (small_levels++ < 3) {
       hipLaunchKernelGGL(bvhb::k_level<256>, dim3(n_active), dim3(256), 0, c->stream, B, (const uint32_t*)nullptr, id0, n_active);
+    } else {
+      // deep levels: tens of thousands of nodes of a few dozen triangles, and the sweep of a node is one lane's work —
+      // one wave per node keeps four times as many nodes in flight per CU
+      hipLaunchKernelGGL(bvhb::k_level<64>, dim3(n_active), dim3(64), 0, c->stream, B, (const uint32_t*)nullptr, id0, n_active);
     }
-    uint32_t next_total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&next_total, B.counters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(pinned_counter, B.counters, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    const uint32_t next_total = *pinned_counter;
     if (next_total > max_nodes || next_total < total) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
     id0 = total;
     n_active = next_total - total;
