@@ -165,7 +165,8 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
 int rt_set_kernel_timing(rt_ctx* ctx, int enabled);
 /* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
- *   3 = auto (default): persistent kernel when the scene's records fit LDS, wavefront form otherwise (SPP == 1)
+ *   3 = auto (default): wavefront form when the scene's records do not fit LDS, SPP == 1 and the dispatch carries
+ *       >= 4 frames (rt_compute_batch); the persistent kernel otherwise
  *   2 = wavefront: shade / trace stages per depth, path state in HBM, ray-level regeneration in the trace kernels
  *       (SPP != 1 falls back to the persistent kernel)
  *   1 = persistent waves with per-lane path regeneration

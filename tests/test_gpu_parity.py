@@ -319,7 +319,7 @@ def test_wavefront_form_with_stripes(W, gpu_renderer, variant):
     """Sharded render of a scene that does not fit LDS (auto = wavefront form): the ranks' stripes sum to the
     unsharded image bit for bit, in batched and single dispatches."""
     b = pu.bridge_for(W, "sponza_like")
-    w, h, frames = 80, 72, tuple(range(1, 5))
+    w, h, frames = 80, 72, tuple(range(1, 6))
     gpu_renderer.setKernelVariant(1)
     pu.drive(gpu_renderer, W, b, w, h, 6, 1, frames, present=False)
     full = gpu_renderer.readAccum()
@@ -330,8 +330,8 @@ def test_wavefront_form_with_stripes(W, gpu_renderer, variant):
         r.setStripes(16, rank, 3)
         r.buildPipeline(6, 1)
         W.upload_scene(r, b, w, h)
-        r.computeBatch(frames[:3])
-        r.compute(frames[3])
+        r.computeBatch(frames[:4])     # auto: >= 4 frames per dispatch -> wavefront form
+        r.compute(frames[4])           # auto: a single frame -> persistent kernel
         total += r.readAccum()
         r.destroy()
     assert np.array_equal(total.view(np.uint32), full.view(np.uint32))

@@ -820,7 +820,9 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   const size_t npx = (size_t)c->width * c->height;
   const size_t scene_lds = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
   const bool fits_lds = scene_lds + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
-  const bool wavefront = c->spp == 1 && (c->variant == 2 || (c->variant == 3 && !fits_lds));
+  // auto: the wavefront form pays from 4 frames per dispatch (measured: 1 frame 11.9 vs 8.7 ms persistent, 2: 17.0 vs
+  // 15.7, 4: 27.8 vs 29.5, 8: 47.9 vs 57.0 on sponza-like) — a single frame leaves its deeper stages too few rays
+  const bool wavefront = c->spp == 1 && (c->variant == 2 || (c->variant == 3 && !fits_lds && n >= 4));
   if (n > 1) {
     r = ensure_buffer(c, c->gbuf_batch, (size_t)(n - 1) * npx * 24, false);
     if (r < 0) return r;
