@@ -61,7 +61,7 @@ def build_scene(force=False):
     if not force and _newer(SCENE_LIB, deps):
         return SCENE_LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", SCENE_LIB, src]
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", SCENE_LIB, src]
     subprocess.run(cmd, check=True)
     return SCENE_LIB
 

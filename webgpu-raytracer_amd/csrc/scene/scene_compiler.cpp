@@ -23,6 +23,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1074,6 +1075,28 @@ struct ms_world {
 
 static thread_local std::string g_last_error;
 
+// Index-parallel host loop for the per-vertex / per-triangle passes of world_update (the reference runs them on one
+// thread; every index writes its own output slot, so the result does not depend on the split).
+template <class F>
+static void parallel_for(size_t n, F&& body) {
+  const size_t kMinPerThread = 16384;
+  size_t threads = std::thread::hardware_concurrency();
+  if (threads > 16) threads = 16;
+  if (threads > n / kMinPerThread) threads = n / kMinPerThread;
+  if (threads <= 1) {
+    body((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t step = (n + threads - 1) / threads;
+  for (size_t t = 0; t < threads; t++) {
+    const size_t lo = t * step, hi = std::min(n, lo + step);
+    if (lo >= hi) break;
+    pool.emplace_back([&body, lo, hi]() { body(lo, hi); });
+  }
+  for (std::thread& th : pool) th.join();
+}
+
 // lib.rs:383-491 apply_animation: sample every channel of one animation at `time` into the nodes' local TRS
 static void apply_animation(ms_world& w, size_t anim_idx, float time_in) {
   const GAnimation& anim = w.gltf.animations[anim_idx];
@@ -1180,7 +1203,8 @@ static void world_update(ms_world& w, float time = 0.0f) {
     if (skin)
       for (size_t k = 0; k < skin->joints.size() && k < skin->inverse_bind.size(); k++)
         joint_mats.push_back(m4_mul(skin->joints[k] < globals.size() ? globals[skin->joints[k]] : m4_identity(), skin->inverse_bind[k]));
-    for (size_t i = 0; i < geo.positions.size(); i++) {
+    parallel_for(n_geo_verts, [&](size_t lo_i, size_t hi_i) {
+    for (size_t i = lo_i; i < hi_i; i++) {
       V3 p = geo.positions[i], n = geo.normals[i];
       V2 uv = i < geo.uvs.size() ? geo.uvs[i] : V2{0, 0};
       if (skin) {
@@ -1207,6 +1231,7 @@ static void world_update(ms_world& w, float time = 0.0f) {
       uv2[i * 2] = uv.x;
       uv2[i * 2 + 1] = uv.y;
     }
+    });
     // BLAS: nodes (8 f32 each, BLAS-local skips) + triangle order, from the CPU builder or from the hook
     std::vector<float>& packed = w.scratch_nodes;  // reused between updates: no 17 MB of zero-fill per frame
     std::vector<uint32_t>& order = w.scratch_order;
@@ -1244,15 +1269,20 @@ static void world_update(ms_world& w, float time = 0.0f) {
       }
     }
     w.topology.resize(w.topology.size() + (size_t)n_tris * 20);
-    for (size_t i = 0; i < n_tris; i++) {
-      size_t old_id = order[i];
-      uint32_t* row = &w.topology[((size_t)topo_start + i) * 20];
-      row[0] = geo.indices[old_id * 3] + v_offset;
-      row[1] = geo.indices[old_id * 3 + 1] + v_offset;
-      row[2] = geo.indices[old_id * 3 + 2] + v_offset;
-      row[3] = (uint32_t)gi;
-      std::memcpy(&row[4], &geo.attributes[old_id * 16], 64);
-      float mat_val = geo.attributes[old_id * 16 + 3];
+    uint32_t* topo_rows = &w.topology[(size_t)topo_start * 20];
+    parallel_for(n_tris, [&](size_t lo_i, size_t hi_i) {
+      for (size_t i = lo_i; i < hi_i; i++) {
+        size_t old_id = order[i];
+        uint32_t* row = topo_rows + i * 20;
+        row[0] = geo.indices[old_id * 3] + v_offset;
+        row[1] = geo.indices[old_id * 3 + 1] + v_offset;
+        row[2] = geo.indices[old_id * 3 + 2] + v_offset;
+        row[3] = (uint32_t)gi;
+        std::memcpy(&row[4], &geo.attributes[old_id * 16], 64);
+      }
+    });
+    for (size_t i = 0; i < n_tris; i++) {  // emissive triangles, in topology order (rebuilder.rs:163-168)
+      float mat_val = geo.attributes[(size_t)order[i] * 16 + 3];
       if (std::fabs(mat_val - 3.0f) < 1e-6f) emissive[gi].push_back(topo_start + (uint32_t)i);
     }
     w.blas.insert(w.blas.end(), packed.begin(), packed.begin() + (long)n_packed * 8);
