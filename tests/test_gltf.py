@@ -396,3 +396,17 @@ def test_gpu_blas_builder_equals_the_cpu_builder(W):
             for k in BRIDGE_ARRAYS:
                 assert np.array_equal(np.asarray(getattr(cpu_b, k)).view(np.uint32), np.asarray(getattr(gpu_b, k)).view(np.uint32)), (scene, t, k)
     r.destroy()
+
+
+@pytest.mark.gpu
+def test_builder_hook_refuses_a_destroyed_renderer(W):
+    r = W.WebGPURenderer(0)
+    b = W.WorldBridge()
+    b.setBlasBuilder(r)
+    b.loadScene("cornell")
+    b.update(0.0)
+    r.destroy()
+    with pytest.raises(RuntimeError):
+        b.update(0.1)
+    b.setBlasBuilder(None)
+    b.update(0.1)

@@ -143,6 +143,7 @@ class WorldBridge {
     this.hasNewGeometry = true;
   }
   update(time) {
+    if (this._blasRenderer && !this._blasRenderer._ctx) throw new Error('the renderer set with setBlasBuilder() has been destroyed');
     native.msUpdate(this._w, time);
     if (this._blasRenderer) {
       const err = native.msLastError();

@@ -118,7 +118,7 @@ class WorldBridge:
         if not self._world:
             return
         r = self._blas_renderer
-        if r is None:
+        if r is None or not r.ctx:
             self._lib.ms_world_set_blas_builder(self._world, None, None)
         else:
             fn = ctypes.cast(r.L.rt_build_blas, ctypes.c_void_p)
@@ -126,6 +126,8 @@ class WorldBridge:
 
     # world-bridge.ts:141-145
     def update(self, time):
+        if self._blas_renderer is not None and not self._blas_renderer.ctx:
+            raise RuntimeError("the renderer set with setBlasBuilder() has been destroyed")
         self._lib.ms_world_update(self._world, float(time))
         if self._blas_renderer is not None:
             err = self._lib.ms_last_error().decode()
