@@ -64,13 +64,16 @@ struct DevFrameSlot {
 };
 
 // Wavefront form (large scenes): path state lives in HBM between the shade and trace stages.
-struct WfState {      // SoA planes, one element per (frame, pixel) item
-  float4* a;          // ro.xyz, hit_t
-  float4* b;          // rd.xyz, prev_bsdf_pdf
-  float4* c;          // throughput.xyz, bitcast(rng)
-  float4* d;          // radiance.xyz, bitcast(flags): depth | specular << 8 | ended << 9 | nee_valid << 10
-  float4* e;          // pending NEE term .xyz, bitcast(tri)
-  uint32_t* inst;
+struct WfPath {       // one 96-B record per (frame, pixel) item: after the first bounce the live paths are visited in
+  float4 a;           // queue order, i.e. scattered — a record is three 32-B sectors instead of six planes' worth
+  float4 b;           // a: ro.xyz, hit_t   b: rd.xyz, prev_bsdf_pdf   c: throughput.xyz, bitcast(rng)
+  float4 c;           // d: radiance.xyz, bitcast(flags): depth | specular << 8 | ended << 9 | nee_valid << 10
+  float4 d;           // e: pending NEE term .xyz, bitcast(tri)
+  float4 e;
+  uint32_t inst, pad[3];
+};
+struct WfState {
+  WfPath* p;
 };
 struct WfQueues {
   uint32_t* active[2];    // path ids alive at the current / next depth

@@ -9,7 +9,7 @@ namespace rtk {
 // For scenes whose traversal records do not fit LDS (hundreds of thousands of triangles, a thousand instances) a ray
 // visits 70+ nodes with a long tail, and the per-trip lockstep of the persistent kernel leaves 60 % of the lanes idle
 // while they wait on L2 / Infinity-Cache latency.  The wavefront form splits a bounce into stages with the path state in
-// HBM (84 B per path, 288 GB to spare):
+// HBM (one 96-B record per path, 288 GB to spare):
 //   k_wf_shade   one lane per live path: surface frame + shade_bounce(); appends the shadow ray and the extension ray
 //                to device queues (wave-aggregated atomics), finishes paths that end
 //   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result and pulls the
@@ -55,11 +55,11 @@ __device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* id
 
 __device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
                                               rt3 nee) {
-  W.a[id] = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
-  W.b[id] = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
-  W.c[id] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
-  W.d[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
-  W.e[id] = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
+  W.p[id].a = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
+  W.p[id].b = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
+  W.p[id].c = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
+  W.p[id].d = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
+  W.p[id].e = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
 }
 
 template <bool FIRST, bool DETAIL>
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
         setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
       }
     } else {
-      const float4 a = W.a[id], b = W.b[id], c = W.c[id], d = W.d[id], e = W.e[id];
+      const float4 a = W.p[id].a, b = W.p[id].b, c = W.p[id].c, d = W.p[id].d, e = W.p[id].e;
       p.ro = xyz(a);
       p.hit_t = a.w;
       p.rd = xyz(b);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
       p.depth = fl & 0xffu;
       p.specular = (fl & WF_FLAG_SPECULAR) != 0u;
       p.tri = rt_f2u(e.w);
-      p.inst = W.inst[id];
+      p.inst = W.p[id].inst;
       setup_surface(S, p, false, 0.0f, 0.0f, 0u);
     }
     if (live) {
@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
       bool push_next = false;
       if (done) {
         if (ANY) {
-          float4 dd = Ws.d[id];
+          float4 dd = Ws.p[id].d;
           const uint32_t fl = rt_f2u(dd.w);
           if (!any && (fl & WF_FLAG_NEE_VALID) != 0u) {
-            const float4 e = Ws.e[id];
+            const float4 e = Ws.p[id].e;
             dd.x = dd.x + e.x;  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
             dd.y = dd.y + e.y;
             dd.z = dd.z + e.z;
@@ -258,23 +258,23 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
           if ((fl & WF_FLAG_ENDED) != 0u)
             F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
           else
-            Ws.d[id] = dd;
+            Ws.p[id].d = dd;
         } else {
           if (best_inst < 0) {  // miss: the path ends with what it has
-            const float4 dd = Ws.d[id];
+            const float4 dd = Ws.p[id].d;
             F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
           } else {
-            float4 a = Ws.a[id];
+            float4 a = Ws.p[id].a;
             a.w = closest;
-            Ws.a[id] = a;
-            float4 e = Ws.e[id];
+            Ws.p[id].a = a;
+            float4 e = Ws.p[id].e;
             e.w = rt_u2f((uint32_t)best_tri);
-            Ws.e[id] = e;
-            Ws.inst[id] = (uint32_t)best_inst;
-            float4 dd = Ws.d[id];
+            Ws.p[id].e = e;
+            Ws.p[id].inst = (uint32_t)best_inst;
+            float4 dd = Ws.p[id].d;
             const uint32_t fl = rt_f2u(dd.w);
             dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
-            Ws.d[id] = dd;
+            Ws.p[id].d = dd;
             push_next = true;
           }
         }
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
                 d = xyz(r1);
                 t_max = r0.w;
               } else {
-                o = xyz(Ws.a[id]);
-                d = xyz(Ws.b[id]);
+                o = xyz(Ws.p[id].a);
+                d = xyz(Ws.p[id].b);
                 t_max = RT_T_MAX;
               }
               n_traced++;

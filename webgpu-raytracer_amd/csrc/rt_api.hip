@@ -710,7 +710,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   const size_t npx = (size_t)c->width * c->height;
   const size_t items = npx * n;
   if (items >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "batch too large for the wavefront queues");
-  int r = ensure_buffer(c, c->wf_state, items * 84, false);
+  int r = ensure_buffer(c, c->wf_state, items * sizeof(WfPath), false);
   if (r < 0) return r;
   // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
   const size_t qcap = items + (size_t)5 * 1024 * 1024;
@@ -721,13 +721,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   if (r < 0) return r;
   HIP_TRY(c, hipMemsetAsync(c->wf_counters.ptr, 0, (size_t)(depths + 1) * 32, c->stream));
   WfState W;
-  char* sb = (char*)c->wf_state.ptr;
-  W.a = (float4*)sb;
-  W.b = (float4*)(sb + items * 16);
-  W.c = (float4*)(sb + items * 32);
-  W.d = (float4*)(sb + items * 48);
-  W.e = (float4*)(sb + items * 64);
-  W.inst = (uint32_t*)(sb + items * 80);
+  W.p = (WfPath*)c->wf_state.ptr;
   WfQueues Q;
   char* qb = (char*)c->wf_queues.ptr;
   Q.shadow_rays = (float4*)qb;
