@@ -6,7 +6,7 @@ Step     : one full image = resetAccumulation + 64 x compute(frame_count = 1..64
            SPP = 1 (the canonical decomposition) + one present().
 Rays     : primary-visibility casts + extension rays + shadow rays actually traced, from the
            device counters (deterministic; cross-checked against the oracle in tests/).
-N > 1    : the image is split into interleaved 16-row stripes across ranks (strong scaling of one
+N > 1    : the image is split into interleaved 8-row stripes across ranks (strong scaling of one
            image), one RCCL sum-reduce of the float4 accumulation buffer to rank 0 per image.
 Extra    : "roofline" for the dominant kernel (k_pathtrace; HIP events inside the C library, on the
            stream the kernel runs on) and "cpu_baseline" (the CPU oracle timed on a bounded
@@ -190,7 +190,7 @@ def main():
             "config": {"workload": "cornell box 1920x1080, 64 spp as 1 spp x 64 compute() frames (frame_count 1..64, "
                                    "issued as batched dispatches of %d frames), depth 8, one present() per image" % args.batch,
                        "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
-                       "parallelism": "16-row stripes x %d ranks + 1 RCCL reduce/image" % world if world > 1 else "1 GPU",
+                       "parallelism": "%d-row stripes x %d ranks + 1 RCCL reduce/image" % (rtdist.STRIPE_ROWS, world) if world > 1 else "1 GPU",
                        "frames_per_dispatch": args.batch, "rays_per_image": int(rays_total / args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_pathtrace_persistent", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
