@@ -257,3 +257,39 @@ def test_ingested_scene_textures_equal_direct_upload(W, gpu_renderer):
     gpu_renderer.loadTexturesFromWorld(b)
     for i in range(b.textureCount):
         assert np.array_equal(gpu_renderer.readTextureLayer(i), b.getTextureRGBA(i))
+
+
+def test_decoders_survive_mutated_input(W):
+    """Byte-level mutations of valid PNG / JPEG files either decode or are refused — never crash (the sanitizer build of
+    the same loop is tools/fuzz/run.sh: ASan + UBSan, 64 k mutations clean)."""
+    rng = np.random.default_rng(13)
+    seeds = []
+    im = PIL.fromarray(smooth(rng, 24, 31, 3), "RGB")
+    for kw in (dict(format="PNG"), dict(format="PNG", optimize=True), dict(format="JPEG", quality=70), dict(format="JPEG", progressive=True, subsampling=2)):
+        bio = io.BytesIO()
+        im.save(bio, **kw)
+        seeds.append(bio.getvalue())
+    decoded = refused = 0
+    for seed in seeds:
+        for _ in range(400):
+            d = bytearray(seed)
+            for _ in range(int(rng.integers(1, 6))):
+                k = int(rng.integers(0, 4))
+                p = int(rng.integers(0, len(d)))
+                if k == 0:
+                    d[p] ^= 1 << int(rng.integers(0, 8))
+                elif k == 1:
+                    d[p] = int(rng.integers(0, 256))
+                elif k == 2:
+                    del d[p:]
+                    if not d:
+                        d = bytearray(b"\0")
+                else:
+                    d[p:p] = bytes([int(rng.integers(0, 256))])
+            try:
+                img = W.textures.decode_image(bytes(d))
+                assert img.ndim == 3 and img.shape[2] == 4
+                decoded += 1
+            except W.textures.ImageDecodeError:
+                refused += 1
+    assert decoded + refused == 1600 and refused > 0

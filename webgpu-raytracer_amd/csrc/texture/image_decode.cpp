@@ -510,7 +510,7 @@ void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) 
     const uint16_t* qp = q + c;
     long* wp = ws + c;
     if (ip[8] == 0 && ip[16] == 0 && ip[24] == 0 && ip[32] == 0 && ip[40] == 0 && ip[48] == 0 && ip[56] == 0) {
-      long dc = ((long)ip[0] * qp[0]) << PASS1_BITS;
+      long dc = ((long)ip[0] * qp[0]) * (1L << PASS1_BITS);  // (a shift of a negative value is undefined before C++20)
       for (int r = 0; r < 8; r++) wp[8 * r] = dc;
       continue;
     }
@@ -520,7 +520,7 @@ void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) 
     long tmp3 = z1 + z2 * JFIX_0_765366865;
     z2 = (long)ip[0] * qp[0];
     z3 = (long)ip[32] * qp[32];
-    long tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+    long tmp0 = (z2 + z3) * (1L << CONST_BITS), tmp1 = (z2 - z3) * (1L << CONST_BITS);
     long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = (long)ip[56] * qp[56];
     tmp1 = (long)ip[40] * qp[40];
@@ -566,7 +566,7 @@ void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) 
     long z1 = (z2 + z3) * JFIX_0_541196100;
     long tmp2 = z1 + z3 * (-JFIX_1_847759065);
     long tmp3 = z1 + z2 * JFIX_0_765366865;
-    long tmp0 = (wp[0] + wp[4]) << CONST_BITS, tmp1 = (wp[0] - wp[4]) << CONST_BITS;
+    long tmp0 = (wp[0] + wp[4]) * (1L << CONST_BITS), tmp1 = (wp[0] - wp[4]) * (1L << CONST_BITS);
     long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = wp[7];
     tmp1 = wp[5];
