@@ -115,7 +115,10 @@ int rt_set_scene(rt_ctx* ctx, const float camera[24], uint32_t frame_count, uint
 /* recreateBindGroup() — WebGPURenderer.ts:82-86.  Nothing to rebind on HIP; kept for call parity. */
 int rt_recreate_bind_group(rt_ctx* ctx);
 
-/* compute(frameCount) — WebGPURenderer.ts:88-102: totalFrames++, frame uniforms (Halton jitter),
+/* The first compute() after an upload checks every index the kernels follow (vertex ids, skip pointers, leaf ranges,
+ * instance BLAS offsets, light references) on the GPU and returns RT_ERR_INVALID with the reason for a malformed scene —
+ * the stand-in for WebGPU's robust buffer access, which a HIP kernel does not have.
+ * compute(frameCount) — WebGPURenderer.ts:88-102: totalFrames++, frame uniforms (Halton jitter),
  * primary-visibility pass, path-trace pass.  Enqueues on the context stream. */
 int rt_compute(rt_ctx* ctx, uint32_t frame_count);
 

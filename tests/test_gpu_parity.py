@@ -360,3 +360,55 @@ def test_kernel_forms_agree_bitwise(W):
             assert np.array_equal(ref[0], got[0]), "variant %d accumulation differs" % variant
             assert np.array_equal(ref[1], got[1])
             assert ref[2] == got[2]
+
+
+def test_malformed_scene_arrays_are_refused_not_followed(W, gpu_renderer):
+    """WebGPU's robust buffer access keeps the reference alive on a bad index; a HIP kernel would fault or spin. Every
+    index the kernels follow is checked once per upload (k_validate_scene) and compute() fails with the reason."""
+    b = pu.bridge_for(W, "mixed")
+    r = gpu_renderer
+    r.buildPipeline(4, 1)
+    W.upload_scene(r, b, 48, 32)
+    r.compute(1)
+    r.sync()
+    n_verts, n_tris = len(b.vertices) // 4, len(b.mesh_topology) // 20
+    n_inst = len(b.instances) // 36
+
+    def expect_refusal(what):
+        with pytest.raises(W.RendererError, match="out of range"):
+            r.compute(2)
+        r.sync()
+        assert what in str(r.L.rt_last_error(r.ctx))
+
+    topo = np.array(b.mesh_topology, dtype=np.uint32)
+    topo[20 * 5 + 1] = n_verts                      # a vertex id one past the end
+    r.updateBuffer("topology", topo)
+    expect_refusal("1 triangles")
+    r.updateBuffer("topology", b.mesh_topology)
+    blas = np.array(b.blas, dtype=np.float32)
+    blas[8 * 2 + 3:8 * 2 + 4].view(np.uint32)[0] = 1  # skip pointer that goes backwards: the walk would never end
+    r.updateCombinedBVH(b.tlas, blas)
+    expect_refusal("1 BLAS nodes")
+    blas = np.array(b.blas, dtype=np.float32)
+    leaf = int(np.flatnonzero(blas.view(np.uint32)[7::8])[0])
+    blas.view(np.uint32)[leaf * 8 + 7] = ((n_tris - 1) << 3) | 3   # a leaf whose triangle range runs past the topology
+    r.updateCombinedBVH(b.tlas, blas)
+    expect_refusal("1 BLAS nodes")
+    tlas = np.array(b.tlas, dtype=np.float32)
+    tl = int(np.flatnonzero(tlas.view(np.uint32)[7::8])[0])
+    tlas.view(np.uint32)[tl * 8 + 7] = (n_inst << 3) | 1           # a TLAS leaf naming an instance that does not exist
+    r.updateCombinedBVH(tlas, b.blas)
+    expect_refusal("1 TLAS nodes")
+    r.updateCombinedBVH(b.tlas, b.blas)
+    inst = np.array(b.instances, dtype=np.float32)
+    inst.view(np.uint32)[32] = len(b.blas) // 8 + 5                # BLAS offset outside the node buffer
+    r.updateBuffer("instance", inst)
+    expect_refusal("1 instances")
+    r.updateBuffer("instance", b.instances)
+    lights = np.array(b.lights, dtype=np.uint32)
+    lights[1] = n_tris
+    r.updateBuffer("lights", lights)
+    expect_refusal("1 light references")
+    r.updateBuffer("lights", b.lights)
+    r.compute(2)                                                   # the intact scene renders again
+    r.sync()

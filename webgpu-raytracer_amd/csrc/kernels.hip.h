@@ -9,6 +9,7 @@
 //   k_pathtrace.hip.h         Raytracer.wgsl `main` + ray_color (:607-819): k_pathtrace, k_pathtrace_persistent
 //   k_wavefront.hip.h         the same bounce as shade / trace stages over device queues (large scenes)
 //   k_texture_post.hip.h      k_resize_texture; k_postprocess = PostProcess.wgsl `main` (:103-176)
+//   k_validate.hip.h          k_validate_scene: every index the kernels follow, checked once per upload
 //
 // All arithmetic is unfused IEEE f32 (-ffp-contract=off) with the builtin semantics of
 // include/mi355rt_math.h, in the evaluation order of the WGSL source, so that every path
@@ -29,5 +30,6 @@
 #include "k_pathtrace.hip.h"
 #include "k_wavefront.hip.h"
 #include "k_texture_post.hip.h"
+#include "k_validate.hip.h"
 
 #endif

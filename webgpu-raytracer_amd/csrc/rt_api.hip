@@ -51,6 +51,10 @@ struct rt_ctx {
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
+  bool validate_dirty = true, scene_valid = false;  // k_validate_scene: run once per upload
+  std::string scene_problem;
+  std::vector<uint32_t> blas_roots;                 // sorted unique BLAS-local root offsets of the instances
+  DeviceBuffer val_roots, val_bad;
   uint32_t n_tris = 0, n_instances = 0, n_lights = 0, n_verts = 0, n_nodes = 0, tex_layers = 0;
   std::vector<uint32_t> draw_commands_host;  // kept like ResourceManager.drawCommandsArray
 
@@ -192,7 +196,53 @@ float4* accum_ptr(rt_ctx* c) { return (float4*)(c->external_accum ? c->external_
 
 DevScene dev_scene(const rt_ctx* c);
 
+// Every index the kernels follow, checked on the GPU once per upload (k_validate.hip.h): a malformed scene is refused
+// here instead of faulting or hanging a kernel.
+static int validate_scene(rt_ctx* c) {
+  if (!c->validate_dirty) return c->scene_valid ? RT_OK : fail(c, RT_ERR_INVALID, c->scene_problem.c_str());
+  int r = ensure_buffer(c, c->val_bad, 32, false);
+  if (r < 0) return r;
+  r = ensure_buffer(c, c->val_roots, std::max<size_t>(4, c->blas_roots.size() * 4), false);
+  if (r < 0) return r;
+  HIP_TRY(c, hipMemsetAsync(c->val_bad.ptr, 0, 32, c->stream));
+  if (!c->blas_roots.empty())
+    HIP_TRY(c, hipMemcpyAsync(c->val_roots.ptr, c->blas_roots.data(), c->blas_roots.size() * 4, hipMemcpyHostToDevice, c->stream));
+  rtk::ValidateArgs A;
+  A.topo = (const float4*)c->topology.ptr;
+  A.nodes = (const float4*)c->nodes.ptr;
+  A.inst = (const float4*)c->instances.ptr;
+  A.lights = (const uint2*)c->lights.ptr;
+  A.roots = (const uint32_t*)c->val_roots.ptr;
+  A.n_tris = c->n_tris;
+  A.n_verts = c->n_verts;
+  A.n_nodes = c->n_nodes;
+  A.n_tlas = c->blas_offset;
+  A.n_inst = c->n_instances;
+  A.n_lights = c->n_lights;
+  A.n_roots = (uint32_t)c->blas_roots.size();
+  A.bad = (uint32_t*)c->val_bad.ptr;
+  const uint32_t n = std::max(std::max(c->n_tris, c->n_nodes), std::max(c->n_instances, c->n_lights));
+  if (n) hipLaunchKernelGGL(rtk::k_validate_scene, dim3((n + 255) / 256), dim3(256), 0, c->stream, A);
+  HIP_TRY(c, hipGetLastError());
+  uint32_t bad[5] = {0, 0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(bad, c->val_bad.ptr, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->validate_dirty = false;
+  c->scene_valid = !(bad[0] | bad[1] | bad[2] | bad[3] | bad[4]);
+  if (!c->scene_valid) {
+    c->scene_problem = "scene arrays refer to elements out of range: " + std::to_string(bad[0]) + " triangles (vertex ids), " +
+                       std::to_string(bad[1]) + " TLAS nodes, " + std::to_string(bad[2]) + " BLAS nodes, " +
+                       std::to_string(bad[3]) + " instances (BLAS offset), " + std::to_string(bad[4]) + " light references";
+    return fail(c, RT_ERR_INVALID, c->scene_problem.c_str());
+  }
+  return RT_OK;
+}
+
 int prepare_scene(rt_ctx* c) {
+  {
+    int r = validate_scene(c);
+    if (r < 0) return r;
+  }
   if (c->tris_dirty && c->n_tris && c->n_verts) {
     int r = ensure_buffer(c, c->tri_geom, (size_t)c->n_tris * 48, true);
     if (r < 0) return r;
@@ -324,7 +374,7 @@ void rt_destroy(rt_ctx* c) {
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
-                         &c->bv_counters, &c->bv_big};
+                         &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -616,6 +666,7 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       r = upload(c, c->topology, data, bytes);
       if (r < 0) return r;
       c->n_tris = (uint32_t)(bytes / sizeof(rt_topology));
+      c->validate_dirty = true;
       c->tris_dirty = true;
       c->lights_dirty = true;
       return r;
@@ -624,6 +675,14 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       r = upload(c, c->instances, data, bytes);
       if (r < 0) return r;
       c->n_instances = (uint32_t)(bytes / sizeof(rt_instance));
+      {  // BLAS roots the instances refer to (host copy of one word per instance: the validation kernel needs them sorted)
+        const rt_instance* hi = (const rt_instance*)data;
+        c->blas_roots.resize(c->n_instances);
+        for (uint32_t k = 0; k < c->n_instances; k++) c->blas_roots[k] = hi[k].blas_node_offset;
+        std::sort(c->blas_roots.begin(), c->blas_roots.end());
+        c->blas_roots.erase(std::unique(c->blas_roots.begin(), c->blas_roots.end()), c->blas_roots.end());
+      }
+      c->validate_dirty = true;
       c->inst_dirty = true;
       c->lights_dirty = true;
       return r;
@@ -632,6 +691,7 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       r = upload(c, c->lights, data, bytes);
       if (r < 0) return r;
       c->n_lights = (uint32_t)(bytes / sizeof(rt_light_ref));
+      c->validate_dirty = true;
       c->lights_dirty = true;
       return r;
     case RT_KIND_DRAW_COMMANDS: {
@@ -668,6 +728,7 @@ int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const fl
   if (r2 < 0) return r2;
   c->n_verts = vertex_count;
   c->vertex_count = vertex_count;
+  c->validate_dirty = true;
   c->tris_dirty = true;
   c->lights_dirty = true;
   return (r0 | r1 | r2) ? RT_REALLOCATED : RT_OK;
@@ -688,6 +749,7 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->blas_offset = n_tlas;  // this.blasOffset = tlas.length / 8
   c->n_nodes = n_tlas + n_blas;
+  c->validate_dirty = true;
   return r ? RT_REALLOCATED : RT_OK;
 }
 
