@@ -51,9 +51,40 @@ __global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __r
 }
 
 // ================================================================ primary visibility
-template <bool DETAIL>
-__global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame F, rt_scene_uniforms U,
-                                                           const DevFrameSlot* __restrict__ slots) {
+// 16-byte LDS slots of the records this kernel reads (nodes, triangle records, instance rows, topology, normals, uvs)
+__host__ __device__ inline size_t primary_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts) {
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)n_verts + ((size_t)n_verts + 1) / 2;
+}
+
+// LDS = false: one wave (one 8x8 tile) per workgroup, records through L1 / L2.  LDS = true (small scenes): four tiles per
+// 256-thread workgroup and the records staged in LDS first — the walk is a chain of dependent fetches, and an LDS
+// fetch returns in a fraction of an L1 hit's time.
+template <bool DETAIL, bool LDS>
+__global__ __launch_bounds__(LDS ? 256 : 64) void k_primary_visibility(DevScene Sg, DevFrame F, rt_scene_uniforms U,
+                                                                       const DevFrameSlot* __restrict__ slots, uint32_t n_tiles,
+                                                                       uint32_t n_nodes_total, uint32_t n_tris_total,
+                                                                       uint32_t n_inst_total, uint32_t n_verts_total) {
+  extern __shared__ float4 s_primary[];
+  DevScene S = Sg;
+  if (LDS) {
+    float4* dst = s_primary;
+    auto stage = [&](const void* src, size_t slots_n) {
+      const float4* g = reinterpret_cast<const float4*>(src);
+      float4* base = dst;
+      for (uint32_t i = threadIdx.x; i < slots_n; i += 256) base[i] = g[i];
+      dst += slots_n;
+      return base;
+    };
+    S.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    S.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    S.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    S.topo = stage(Sg.topo, (size_t)5 * n_tris_total);
+    S.nrm = stage(Sg.nrm, n_verts_total);
+    S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));  // >= 16 B of slack behind uv
+    __syncthreads();
+  }
+  const uint32_t tile_id = LDS ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x;
+  const uint32_t lane_id = threadIdx.x & 63u;
   // batched dispatch: blockIdx.y selects the frame; its jitter and G-buffer planes come from the slot table
   if (slots) {
     const DevFrameSlot sl = slots[blockIdx.y];
@@ -69,14 +100,15 @@ __global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame 
   if (F.own_period) {
     // sharded render with tile-aligned stripes: blockIdx.x enumerates only the tiles of the rows this rank owns
     const uint32_t tiles_x = (U.width + 7u) / 8u;
-    uint32_t trow = blockIdx.x / tiles_x;
+    uint32_t trow = tile_id / tiles_x;
     trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
-    x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u);
-    y = trow * 8u + (threadIdx.x >> 3);
+    x = (tile_id % tiles_x) * 8u + (lane_id & 7u);
+    y = trow * 8u + (lane_id >> 3);
     live = x < U.width && y < U.height;
   } else {
-    live = tile_pixel(U, x, y) && owns_row(F, y);
+    live = tile_pixel(U, tile_id, lane_id, x, y) && owns_row(F, y);
   }
+  live = live && tile_id < n_tiles;
   LaneCounters c = {0, 0, 0, 0, 0, 0};
   if (live) {
     const uint32_t p_idx = y * U.width + x;
@@ -119,7 +151,7 @@ __global__ __launch_bounds__(64) void k_primary_visibility(DevScene S, DevFrame 
       F.depth[p_idx] = z_clip / z_view;
     }
   }
-  flush_counters<DETAIL>(c, F.counters, blockIdx.x + blockIdx.y * 977u);
+  flush_counters<DETAIL>(c, F.counters, tile_id + blockIdx.y * 977u);
 }
 
 }  // namespace rtk

@@ -298,13 +298,14 @@ __device__ __forceinline__ bool owns_row(const DevFrame& F, uint32_t y) {
 }
 
 // One wave = one 8x8 pixel tile (the reference's workgroup shape, RaytracePass.ts:96-103).
-__device__ __forceinline__ bool tile_pixel(const rt_scene_uniforms& U, uint32_t& x, uint32_t& y) {
+__device__ __forceinline__ bool tile_pixel(const rt_scene_uniforms& U, uint32_t tile, uint32_t lane, uint32_t& x, uint32_t& y) {
   const uint32_t tiles_x = (U.width + 7u) / 8u;
-  const uint32_t tile = blockIdx.x;
-  const uint32_t lane = threadIdx.x;
   x = (tile % tiles_x) * 8u + (lane & 7u);
   y = (tile / tiles_x) * 8u + (lane >> 3);
   return x < U.width && y < U.height;
+}
+__device__ __forceinline__ bool tile_pixel(const rt_scene_uniforms& U, uint32_t& x, uint32_t& y) {
+  return tile_pixel(U, blockIdx.x, threadIdx.x, x, y);
 }
 
 }  // namespace rtk

@@ -938,10 +938,21 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   // 1. primary visibility (the reference clears + rasterises the G-buffer every compute()); frame = blockIdx.y
   EventPair* ev = next_events(c, 0);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-  if (c->detailed_counters)
-    hipLaunchKernelGGL(rtk::k_primary_visibility<true>, dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
-  else
-    hipLaunchKernelGGL(rtk::k_primary_visibility<false>, dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots);
+  {
+    const size_t plds = rtk::primary_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts) * 16;
+    const uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts;
+    if (plds <= 32 * 1024) {  // small scene: records staged in LDS, four tiles per workgroup
+      const dim3 grid((ptiles + 3) / 4, n);
+      if (c->detailed_counters)
+        hipLaunchKernelGGL((rtk::k_primary_visibility<true, true>), grid, dim3(256), plds, c->stream, S, Fp, c->uniforms, dslots, ptiles, nn, nt, ni, nv);
+      else
+        hipLaunchKernelGGL((rtk::k_primary_visibility<false, true>), grid, dim3(256), plds, c->stream, S, Fp, c->uniforms, dslots, ptiles, nn, nt, ni, nv);
+    } else if (c->detailed_counters) {
+      hipLaunchKernelGGL((rtk::k_primary_visibility<true, false>), dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots, ptiles, nn, nt, ni, nv);
+    } else {
+      hipLaunchKernelGGL((rtk::k_primary_visibility<false, false>), dim3(ptiles, n), dim3(64), 0, c->stream, S, Fp, c->uniforms, dslots, ptiles, nn, nt, ni, nv);
+    }
+  }
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
 
   // 2. path trace
