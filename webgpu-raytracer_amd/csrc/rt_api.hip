@@ -988,15 +988,8 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     }
     uint32_t blocks = (uint32_t)c->occ_blocks[vi] * (uint32_t)c->num_cus;
     const uint32_t own_tiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;
-    // tiles per wave: 1 = as many waves as there are tiles (up to the resident limit); larger values launch fewer
-    // waves so that each can regenerate lanes from several tiles (only pays when a launch carries many frames)
-    static const uint32_t tiles_per_wave_env = []() {
-      const char* e = getenv("RT_TILES_PER_WAVE");
-      int v = e ? atoi(e) : 0;
-      return (uint32_t)(v < 0 ? 0 : v);
-    }();
-    const uint32_t tiles_per_wave = tiles_per_wave_env ? tiles_per_wave_env : 1u;
-    const uint32_t max_useful = (own_tiles * n + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);  // tickets = tiles x frames
+    // as many waves as there are tickets (tiles x frames), up to the resident limit; fewer, longer-lived waves measured worse
+    const uint32_t max_useful = (own_tiles * n + 3) / 4;
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
     uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts, ns = n;
