@@ -133,3 +133,33 @@ def test_javascript_bridge_loads_a_glb_like_the_python_bridge(W, addon, tmp_path
     assert got["texlen"] == len(br.getTexture(0))
     for k in ("vertices", "normals", "mesh_topology", "tlas", "blas", "instances", "lights"):
         assert hashlib.sha256(np.ascontiguousarray(getattr(br, k)).tobytes()).hexdigest() == got[k], k
+
+
+@needs_node
+@pytest.mark.gpu
+def test_javascript_live_loop_on_an_animated_glb_matches_the_oracle(W, oracle_lib, addon, tmp_path):
+    """node/animate_glb.js: LiveLoop (main.ts renderFrame) over a skinned, animated, textured GLB with the GPU BLAS builder,
+    against the oracle driven by the Python LiveLoop on the same frames."""
+    import test_gltf
+    b, _ = test_gltf.build_skinned(W)
+    b.image_texture(W.textures.encode_png(np.full((4, 4, 4), 180, np.uint8)))
+    b.doc["materials"] = [{"pbrMetallicRoughness": {"metallicFactor": 0.0, "baseColorTexture": {"index": 0}}}]
+    b.doc["meshes"][0]["primitives"][0]["material"] = 0
+    path = tmp_path / "strip.glb"
+    path.write_bytes(b.glb())
+    env = dict(os.environ, RT_NODE_GPU_BLAS="1")
+    out = subprocess.run([node, os.path.join(NODE_DIR, "animate_glb.js"), str(path), "96", "64", "7", "2", "5"],
+                         check=True, capture_output=True, text=True, timeout=600, env=env).stdout
+    got = json.loads(out.strip().splitlines()[-1])
+    br = W.WorldBridge()
+    br.loadScene("viewer", glbData=b.glb())
+    cpu = oracle_lib.OracleRenderer()
+    cpu.buildPipeline(5, 1)
+    cpu.loadTexturesFromWorld(br)
+    cpu.updateScreenSize(96, 64)
+    loop = W.LiveLoop(cpu, br, 96, 64, update_interval=2)
+    for _ in range(7):
+        loop.render_frame()
+    assert got["animations"] == ["bend", "anim"] and got["frameCount"] == loop.frameCount
+    assert hashlib.sha256(cpu.readAccum().tobytes()).hexdigest() == got["accum_sha256"]
+    assert hashlib.sha256(cpu.captureFrame()["data"].tobytes()).hexdigest() == got["rgba_sha256"]

@@ -52,3 +52,13 @@ export class WorldBridge {
   /** encoded image bytes (PNG / JPEG), as world-bridge.ts:101-106 hands them out */
   getTexture(index: number): Uint8Array | undefined;
 }
+
+/** src/main.ts:133-163 — re-upload what the bridge marks as new, reset the accumulation; true when something was uploaded */
+export function syncWorld(renderer: WebGPURenderer, bridge: WorldBridge, width: number, height: number): boolean;
+/** `renderFrame` of src/main.ts:119-181 */
+export class LiveLoop {
+  constructor(renderer: WebGPURenderer, bridge: WorldBridge, width: number, height: number, updateInterval?: number);
+  frameCount: number;
+  totalFrameCount: number;
+  renderFrame(): void;
+}

@@ -195,4 +195,42 @@ class WorldBridge {
   }
 }
 
-module.exports = { WebGPURenderer, WorldBridge, native };
+// src/main.ts:133-163: the per-frame scene sync of the live loop. Returns true when something was uploaded.
+function syncWorld(renderer, bridge, width, height) {
+  if (!bridge.hasNewData) return false;
+  let rebind = false;
+  rebind = renderer.updateCombinedBVH(bridge.tlas, bridge.blas) || rebind;
+  rebind = renderer.updateBuffer('instance', bridge.instances) || rebind;
+  rebind = renderer.updateBuffer('draw_commands', bridge.draw_commands) || rebind;
+  if (bridge.hasNewGeometry) {
+    rebind = renderer.updateCombinedGeometry(bridge.vertices, bridge.normals, bridge.uvs) || rebind;
+    rebind = renderer.updateBuffer('topology', bridge.mesh_topology) || rebind;
+    rebind = renderer.updateBuffer('lights', bridge.lights) || rebind;
+    bridge.hasNewGeometry = false;
+  }
+  bridge.updateCamera(width, height);
+  renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount);
+  if (rebind) renderer.recreateBindGroup();
+  renderer.resetAccumulation();
+  bridge.hasNewData = false;
+  return true;
+}
+
+// `renderFrame` of src/main.ts:119-181 without requestAnimationFrame: every updateInterval frames the world advances to
+// t = totalFrameCount / updateInterval / 60, the scene is re-synced and the accumulation restarts; each call traces and presents
+class LiveLoop {
+  constructor(renderer, bridge, width, height, updateInterval = 0) {
+    Object.assign(this, { renderer, bridge, width, height, updateInterval, frameCount: 0, totalFrameCount: 0 });
+  }
+  renderFrame() {
+    if (this.updateInterval > 0 && this.frameCount >= this.updateInterval)
+      this.bridge.update(this.totalFrameCount / (this.updateInterval || 1) / 60);
+    if (syncWorld(this.renderer, this.bridge, this.width, this.height)) this.frameCount = 0;
+    this.frameCount++;
+    this.totalFrameCount++;
+    this.renderer.compute(this.frameCount);
+    this.renderer.present();
+  }
+}
+
+module.exports = { WebGPURenderer, WorldBridge, LiveLoop, syncWorld, native };
