@@ -2,6 +2,7 @@
 rebuilder.rs:36-91).  The reference has no asset and no test for this path and its parser is an un-vendored crate, so the
 checker is the numpy restatement in tests/gltf_util.py (parity unpinned) — plus GPU = oracle on the resulting arrays."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -410,3 +411,28 @@ def test_builder_hook_refuses_a_destroyed_renderer(W):
         b.update(0.1)
     b.setBlasBuilder(None)
     b.update(0.1)
+
+
+def test_parallel_update_equals_single_threaded(W, tmp_path):
+    """update(t) spreads skinning and topology packing over a pool of host threads; with MS_THREADS=1 (a fresh process)
+    everything runs on the calling thread — the arrays must be the same, byte for byte."""
+    import hashlib
+    import subprocess
+    import sys
+    glb, n_tris = big_skinned_glb(W, 256, 128)          # 65 536 triangles: above the per-thread minimum
+    path = tmp_path / "tube.glb"
+    path.write_bytes(glb)
+    code = ("import sys,hashlib,json;sys.path.insert(0,%r);import numpy as np;import webgpu_raytracer_amd as W;"
+            "b=W.WorldBridge();b.loadScene('viewer',glbData=open(%r,'rb').read());b.update(0.4);"
+            "print(json.dumps({k:hashlib.sha256(np.ascontiguousarray(getattr(b,k)).tobytes()).hexdigest() for k in %r}))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(path), list(BRIDGE_ARRAYS)))
+    import json
+    import os as _os
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                         env=dict(_os.environ, MS_THREADS="1")).stdout
+    single = json.loads(out.strip().splitlines()[-1])
+    b = W.WorldBridge()
+    b.loadScene("viewer", glbData=glb)
+    b.update(0.4)
+    for k in BRIDGE_ARRAYS:
+        assert hashlib.sha256(np.ascontiguousarray(getattr(b, k)).tobytes()).hexdigest() == single[k], k

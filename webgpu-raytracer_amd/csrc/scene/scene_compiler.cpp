@@ -22,6 +22,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1076,25 +1079,106 @@ struct ms_world {
 static thread_local std::string g_last_error;
 
 // Index-parallel host loop for the per-vertex / per-triangle passes of world_update (the reference runs them on one
-// thread; every index writes its own output slot, so the result does not depend on the split).
+// thread; every index writes its own output slot, so the result does not depend on the split).  A small pool of
+// worker threads is started on first use and kept: an animated scene calls this twice per frame.
+class WorkerPool {
+ public:
+  static WorkerPool& get() {
+    static WorkerPool pool;
+    return pool;
+  }
+  size_t size() const { return workers_.size() + 1; }  // + the calling thread
+  // run job(k) for k = 0..n_jobs-1, job 0 on the calling thread; returns when all are done
+  void run(size_t n_jobs, const std::function<void(size_t)>& job) {
+    if (n_jobs <= 1 || workers_.empty()) {
+      for (size_t k = 0; k < n_jobs; k++) job(k);
+      return;
+    }
+    std::unique_lock<std::mutex> call(call_mutex_);  // one parallel region at a time
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job;
+      n_jobs_ = n_jobs;
+      next_ = 1;
+      pending_ = n_jobs - 1;
+      generation_++;
+    }
+    cv_.notify_all();
+    job(0);
+    for (;;) {  // the caller helps with whatever is left
+      size_t k;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (next_ >= n_jobs_) break;
+        k = next_++;
+      }
+      job(k);
+      std::lock_guard<std::mutex> lk(m_);
+      pending_--;
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  WorkerPool() {
+    size_t n = std::thread::hardware_concurrency();
+    if (n > 16) n = 16;
+    if (const char* e = std::getenv("MS_THREADS")) {  // MS_THREADS=1: everything on the calling thread
+      const long v = std::atol(e);
+      if (v >= 1 && (size_t)v < n) n = (size_t)v;
+    }
+    for (size_t i = 1; i < n; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  void loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || (generation_ != seen && job_ && next_ < n_jobs_); });
+      if (stop_) return;
+      seen = generation_;
+      while (job_ && next_ < n_jobs_) {
+        const size_t k = next_++;
+        const std::function<void(size_t)>* job = job_;
+        lk.unlock();
+        (*job)(k);
+        lk.lock();
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, call_mutex_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t n_jobs_ = 0, next_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
 template <class F>
 static void parallel_for(size_t n, F&& body) {
   const size_t kMinPerThread = 16384;
-  size_t threads = std::thread::hardware_concurrency();
-  if (threads > 16) threads = 16;
-  if (threads > n / kMinPerThread) threads = n / kMinPerThread;
-  if (threads <= 1) {
+  size_t parts = WorkerPool::get().size();
+  if (parts > n / kMinPerThread) parts = n / kMinPerThread;
+  if (parts <= 1) {
     body((size_t)0, n);
     return;
   }
-  std::vector<std::thread> pool;
-  const size_t step = (n + threads - 1) / threads;
-  for (size_t t = 0; t < threads; t++) {
-    const size_t lo = t * step, hi = std::min(n, lo + step);
-    if (lo >= hi) break;
-    pool.emplace_back([&body, lo, hi]() { body(lo, hi); });
-  }
-  for (std::thread& th : pool) th.join();
+  const size_t step = (n + parts - 1) / parts;
+  WorkerPool::get().run(parts, [&](size_t k) {
+    const size_t lo = k * step, hi = std::min(n, lo + step);
+    if (lo < hi) body(lo, hi);
+  });
 }
 
 // lib.rs:383-491 apply_animation: sample every channel of one animation at `time` into the nodes' local TRS
