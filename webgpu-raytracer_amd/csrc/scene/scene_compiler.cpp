@@ -19,9 +19,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <type_traits>
+#include <utility>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -1057,6 +1062,26 @@ class TlasBuilder {
 
 }  // namespace
 
+// std::vector whose resize() leaves new elements uninitialised (default-initialisation instead of value-initialisation)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAllocator<U>;
+  };
+  using std::allocator<T>::allocator;
+  template <class U>
+  void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <class U, class... Args>
+  void construct(U* p, Args&&... args) {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+template <class T>
+using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+
 // ------------------------------------------------------------------ World
 struct ms_world {
   SceneData scene;
@@ -1064,8 +1089,12 @@ struct ms_world {
   std::vector<Aabb> instance_blas_boxes;
   std::vector<uint32_t> blas_root_offsets;
   // bridge arrays (render_buffers.rs:6-17)
-  std::vector<float> vertices, normals, uvs, tlas, blas, instances, camera;
-  std::vector<uint32_t> topology, lights, draw_commands;
+  // the big ones grow with resize() and are then written element by element: no value-initialisation (21 MB of zeros per
+  // update for 262 k triangles otherwise)
+  RawVec<float> vertices, normals, uvs, blas;
+  RawVec<uint32_t> topology;
+  std::vector<float> tlas, instances, camera;
+  std::vector<uint32_t> lights, draw_commands;
   // glTF scene graph (SceneData.nodes / skins / animations) and World.active_anim_index
   GltfScene gltf;
   size_t active_anim = 0;
@@ -1244,7 +1273,25 @@ static void update_globals(const ms_world& w, std::vector<M4>& globals) {
   }
 }
 
+struct PhaseTimer {  // MS_PROFILE=1: per-phase wall time of world_update on stderr
+  bool on = std::getenv("MS_PROFILE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  void lap(int k) {
+    if (!on) return;
+    auto t = std::chrono::steady_clock::now();
+    acc[k] += std::chrono::duration<double, std::milli>(t - t0).count();
+    t0 = t;
+  }
+  ~PhaseTimer() {
+    if (on)
+      std::fprintf(stderr, "world_update: animation+graph %.2f ms, skinning %.2f, BLAS build %.2f, topology %.2f, copies %.2f, instances+TLAS %.2f\n",
+                   acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+  }
+};
+
 static void world_update(ms_world& w, float time = 0.0f) {
+  PhaseTimer pt;
   // --- lib.rs:149-184: animation, then global transforms of the scene graph ---
   if (!w.gltf.animations.empty()) {
     const size_t ai = w.active_anim < w.gltf.animations.size() ? w.active_anim : 0;
@@ -1253,6 +1300,7 @@ static void world_update(ms_world& w, float time = 0.0f) {
   }
   std::vector<M4> globals;
   update_globals(w, globals);
+  pt.lap(0);
 
   // --- rebuilder.rs:9-190: per geometry, vertices + BLAS + topology ---
   w.vertices.clear();
@@ -1316,6 +1364,7 @@ static void world_update(ms_world& w, float time = 0.0f) {
       uv2[i * 2 + 1] = uv.y;
     }
     });
+    pt.lap(1);
     // BLAS: nodes (8 f32 each, BLAS-local skips) + triangle order, from the CPU builder or from the hook
     std::vector<float>& packed = w.scratch_nodes;  // reused between updates: no 17 MB of zero-fill per frame
     std::vector<uint32_t>& order = w.scratch_order;
@@ -1343,6 +1392,7 @@ static void world_update(ms_world& w, float time = 0.0f) {
       n_packed = bb.nodes.size();
       order.assign(bb.order.begin(), bb.order.end());
     }
+    pt.lap(2);
     uint32_t topo_start = (uint32_t)(w.topology.size() / 20);
     for (size_t ni = 0; ni < n_packed; ni++) {  // leaf `first` becomes a global topology index (rebuilder.rs:123-134)
       uint32_t data;
@@ -1369,10 +1419,12 @@ static void world_update(ms_world& w, float time = 0.0f) {
       float mat_val = geo.attributes[(size_t)order[i] * 16 + 3];
       if (std::fabs(mat_val - 3.0f) < 1e-6f) emissive[gi].push_back(topo_start + (uint32_t)i);
     }
+    pt.lap(3);
     w.blas.insert(w.blas.end(), packed.begin(), packed.begin() + (long)n_packed * 8);
     w.blas_root_offsets.push_back(node_offset);
     node_offset += (uint32_t)n_packed;
     geom_ranges[gi] = {topo_start, (uint32_t)(w.topology.size() / 20) - topo_start};
+    pt.lap(4);
   }
 
   // --- lib.rs:194-230: instance transforms, BLAS offsets, local boxes ---
