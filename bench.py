@@ -3,22 +3,27 @@
 
 Metric   : Mrays/s (primary + secondary) at 1920x1080, SPP = 64, depth = 8 (Cornell box).
 Step     : one full image = resetAccumulation + 64 x compute(frame_count = 1..64) with shader
-           SPP = 1 (the canonical decomposition) + one present().
+           SPP = 1 (the canonical decomposition), issued as batched dispatches, + one present().
 Rays     : primary-visibility casts + extension rays + shadow rays actually traced, from the
            device counters (deterministic; cross-checked against the oracle in tests/).
-N > 1    : the image is split into interleaved 8-row stripes across ranks (strong scaling of one
-           image), one RCCL sum-reduce of the float4 accumulation buffer to rank 0 per image.
-Extra    : "roofline" for the dominant kernel (k_pathtrace; HIP events inside the C library, on the
-           stream the kernel runs on) and "cpu_baseline" (the CPU oracle timed on a bounded
-           1/3 row-interleaved sample of the same workload, rank 0 at N = 1 only).
+N > 1    : `python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed.run, before
+           anything in this process touches the GPU); under a launcher (WORLD_SIZE set) it is one of the ranks.
+           The image is split into interleaved 8-row stripes across ranks (strong scaling of one image), one RCCL
+           sum-reduce of the float4 accumulation buffer to rank 0 per image.
+Extra    : "roofline" for the dominant kernel (k_pathtrace_persistent; launch time from HIP events inside the C
+           library, on the stream the kernel runs on), "configs" (BASELINE configs 3 and 4, timed the same way,
+           with the roofline of their dominant kernel k_wf_trace) and "cpu_baseline" (the CPU oracle timed on a
+           bounded row-interleaved sample of the same workload, rank 0 at N = 1 only).
+Fields that cannot be measured from inside this process (PMC counters) are read from profiles/ and every such field
+carries its "source".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "tests")):
@@ -27,52 +32,131 @@ for _p in (REPO, os.path.join(REPO, "tests")):
 
 WIDTH, HEIGHT, SPP_TOTAL, DEPTH = 1920, 1080, 64, 8
 SCENE = "cornell"
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+L2_PEAK_GBS = 34500.0        # aggregate L2 bandwidth, 8 XCDs (MI355X_MICROARCH.md §L2)
+# f32 VALU: 157.3 TFLOP/s spec = 256 CUs x 4 SIMDs x 32 lanes/clk x 2 flop (FMA) x 2.4 GHz, i.e. 78.6 T lane-instructions/s
+VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
+EXTRA_CONFIGS = [  # (BASELINE.json config, scene, frames, depth, images timed)
+    ("3 instanced diamond x1000", "instanced1000", 64, 8, 3),
+    ("4 sponza-like 263k tris, 8 textures", "sponza_like", 64, 8, 3),
+]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs 3 / 4 lines")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start N ranks as fresh child processes (this process has not
+    imported torch or touched the GPU) and pass their exit code on. Rank 0 prints the JSON line to our stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(pkg, bridge, frames):
-    """Time the CPU oracle (C++ scalar restatement, all host threads) on rows
-    {y : (y // 8) % 3 == 0} of the same 1080p frames: a 1/3 row-interleaved sample."""
+    """Time the CPU oracle (C++ scalar restatement) on a bounded row-interleaved sample of the same 1080p frames:
+    all usable host threads on rows (y//8)%3==0, and ONE thread on rows (y//8)%54==0, so that the scaling of the
+    baseline itself is visible."""
+    import numpy as np
     import oracle_lib
-    cpu = oracle_lib.OracleRenderer()
-    cores = oracle_lib.lib().oracle_hardware_threads()
-    cpu.buildPipeline(DEPTH, 1)
-    pkg.upload_scene(cpu, bridge, WIDTH, HEIGHT)
-    cpu.setStripes(8, 0, 3)
-    sample_px = int(((np.arange(HEIGHT) // 8) % 3 == 0).sum()) * WIDTH
-    cpu.resetCounters()
+
+    def run(threads, div):
+        cpu = oracle_lib.OracleRenderer(threads=threads)
+        cpu.buildPipeline(DEPTH, 1)
+        pkg.upload_scene(cpu, bridge, WIDTH, HEIGHT)
+        cpu.setStripes(8, 0, div)
+        px = int(((np.arange(HEIGHT) // 8) % div == 0).sum()) * WIDTH
+        cpu.resetCounters()
+        t0 = time.perf_counter()
+        for f in frames:
+            cpu.compute(f)
+        dt = time.perf_counter() - t0
+        c = cpu.getCounters()
+        return (c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]), dt, px
+
+    cores = int(oracle_lib.lib().oracle_hardware_threads())   # affinity mask and cgroup quota respected
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
+    r1, t1, px1 = run(1, 54)
+    rn, tn, pxn = run(cores, 3)
+    return {"value": round(rn / tn / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "one_thread_value": round(r1 / t1 / 1e6, 3),
+            "per_thread_at_full_width": round(rn / tn / 1e6 / cores, 4),
+            "sched_affinity": affinity, "os_cpu_count": os.cpu_count(),
+            "sample": "rows (y//8)%%3==0 (1/3 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s on %d threads; "
+                      "one thread: rows (y//8)%%54==0 (%d px), %.1f Mrays in %.1f s"
+                      % (pxn, len(frames), DEPTH, rn / 1e6, tn, cores, px1, r1 / 1e6, t1)}
+
+
+def rehearsal(args, rank, world):
+    """BENCH_REHEARSAL=launch: exercise the launcher, the rendezvous and the max-over-ranks reductions without a
+    renderer (the build container has no GPU). Prints a line that cannot be mistaken for a measurement."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    dist.barrier()
     t0 = time.perf_counter()
-    for f in frames:
-        cpu.compute(f)
-    dt = time.perf_counter() - t0
-    c = cpu.getCounters()
-    rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(cores), "kind": "port",
-            "sample": "rows (y//8)%%3==0 (1/3 of 1080p, %d px) x %d frames, depth %d: %.1f Mrays in %.1f s"
-                      % (sample_px, len(frames), DEPTH, rays / 1e6, dt)}
+    time.sleep(0.01 * (rank + 1))
+    dist.barrier()
+    stats = torch.tensor([time.perf_counter() - t0, float(rank + 1)], dtype=torch.float64)
+    tmax, rsum = stats[:1].clone(), stats[1:].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"rehearsal": "launch", "metric": None, "value": None, "n_gpus": world,
+                          "ranks_seen": int(rsum.item() * 2 / (world + 1)), "steps": args.steps, "warmup": args.warmup}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def pmc_reference():
+    """Counter-derived figures committed under profiles/ (PMC passes cannot run inside this process)."""
+    path = os.path.join(REPO, "profiles", "pmc_reference.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=32,
-                    help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))      # nothing GPU-related has been imported yet
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if os.environ.get("BENCH_REHEARSAL") == "launch":
+        return rehearsal(args, rank, world)
+
+    import numpy as np
     import torch
     import webgpu_raytracer_amd as pkg
     from webgpu_raytracer_amd import distributed as rtdist
 
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP renderer has no CPU fallback")
     # Rehearsal switches for a 1-GPU box (never used by the driver): BENCH_ONE_DEVICE=1 puts every rank on
@@ -83,7 +167,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"   # rehearsal: exercise the RCCL calls with one rank
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -97,91 +182,119 @@ def main():
     # in-tree libraries: built by local rank 0 if missing or stale (a no-op otherwise), the others wait
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         pkg._build.build_scene()
+        pkg._build.build_tex()
         pkg._build.build_rt()
-    if world > 1 or force_dist:
+    if distributed:
         dist.barrier()
-    bridge = pkg.WorldBridge()
-    bridge.loadScene(SCENE)
-    r = pkg.WebGPURenderer(local_rank)
-    r.buildPipeline(DEPTH, 1)
-    pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
-    accum_t = rtdist.bind_torch_accum(r, device)
-    shard = rtdist.ShardedImage(r, rank, world,
-                                device_tensor=accum_t if ((world > 1 or force_dist) and backend == "nccl") else None)
-    shard.force_collective = force_dist
-    frames = list(range(1, SPP_TOTAL + 1))
-
-    def step():
-        r.resetAccumulation()
-        shard.render(frames, batch=args.batch)
-        shard.gather(present=True)
 
     def fence():
-        if world > 1 or force_dist:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    r.resetCounters()
-    r.setKernelTiming(True)
-    r.kernelTimeMs()  # drop anything recorded so far
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ktime = r.kernelTimeMs()
-    r.setKernelTiming(False)
-
-    counts = r.getCounters()
-    rays_local = counts["primary_rays"] + counts["extension_rays"] + counts["shadow_rays"]
-    stats = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1 or force_dist:
-        tmax = stats[:1].clone()
+    def reduce_stats(elapsed, rays):
+        if not distributed:
+            return elapsed, float(rays)
+        stats = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        tmax, rsum = stats[:1].clone(), stats[1:].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rsum = stats[1:].clone()
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
-        elapsed, rays_total = float(tmax.item()), float(rsum.item())
-    else:
-        rays_total = float(rays_local)
+        return float(tmax.item()), float(rsum.item())
 
-    if rank == 0:
-        # one extra untimed image with the detailed-counter kernel variant: per-launch algorithmic bytes
-        # of the dominant kernel (counts are deterministic, so they equal the timed launches')
+    def run_workload(scene, frames, depth, steps, warmup, batch):
+        """Time `steps` images of one scene on all ranks; returns the renderer, the sharding and the measurements."""
+        bridge = pkg.WorldBridge()
+        bridge.loadScene(scene)
+        r = pkg.WebGPURenderer(local_rank)
+        r.buildPipeline(depth, 1)
+        pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
+        shard = rtdist.ShardedImage(r, rank, world, device=device, collective_on_device=(backend == "nccl"),
+                                    force_collective=force_dist)
+
+        def step():
+            r.resetAccumulation()
+            shard.render(frames, batch=batch)
+            shard.gather(present=True)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        r.resetCounters()
+        r.setKernelTiming(True)
+        r.kernelTimes()  # drop anything recorded so far
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ktimes = r.kernelTimes()
+        r.setKernelTiming(False)
+        counts = r.getCounters()
+        rays_local = counts["primary_rays"] + counts["extension_rays"] + counts["shadow_rays"]
+        elapsed, rays_total = reduce_stats(elapsed, rays_local)
+        # one extra untimed image with the detailed-counter kernel variant: algorithmic bytes of the path-trace stage
+        # (the counts are deterministic, so they equal the timed launches')
         r.setCounting(True)
         r.resetCounters()
-        shard.render(frames, batch=args.batch)
+        shard.render(frames, batch=batch)
         r.sync()
         kc = r.getKernelCounters(1)
         r.setCounting(False)
+        return {"bridge": bridge, "renderer": r, "shard": shard, "elapsed": elapsed, "rays": rays_total,
+                "ktimes": ktimes, "kc": kc, "steps": steps}
+
+    frames = list(range(1, SPP_TOTAL + 1))
+    head = run_workload(SCENE, frames, DEPTH, args.steps, args.warmup, args.batch)
+    extra = []
+    if not args.no_extra_configs:
+        for name, scene, nframes, depth, images in EXTRA_CONFIGS:
+            m = run_workload(scene, list(range(1, nframes + 1)), depth, images, 1, args.batch)
+            extra.append((name, scene, nframes, depth, m))
+
+    if rank == 0:
+        ref = pmc_reference()
         n_launch = (len(frames) + args.batch - 1) // args.batch   # path-trace launches per image
-        owned_px = int(shard.owned_rows(HEIGHT).sum()) * WIDTH
-        alg_bytes = (32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"] + 344.0 * kc["shaded_hits"]) / n_launch \
-            + (32.0 + 24.0 * min(args.batch, len(frames))) * owned_px  # accumulation read+write once per launch, G-buffer read per frame
-        achieved = alg_bytes / (ktime["pathtrace_ms"] * 1e-3) / 1e9 if ktime["pathtrace_ms"] > 0 else 0.0
-        # HBM bytes per launch from the PMC passes committed under profiles/ (collected by tools/make_profiles.sh,
-        # N = 1 only; counters cannot be read from inside this process)
-        traffic, pmc = None, {}
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            try:
-                pmc = json.load(open(tpath))
-                # the PMC passes were taken at 32 frames per launch; scale to this run's batch size
-                traffic = pmc.get("k_pathtrace_bytes_per_launch")
-                if traffic is not None and pmc.get("frames_per_launch"):
-                    traffic = traffic * min(args.batch, len(frames)) / pmc["frames_per_launch"]
-            except Exception:
-                traffic, pmc = None, {}
+        owned_px = int(head["shard"].owned_rows(HEIGHT).sum()) * WIDTH
+        kt, kc = head["ktimes"], head["kc"]
+        launch_ms = kt["pathtrace"]["ms"] / max(1, kt["pathtrace"]["launches"])
+        gather_bytes = (32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"] + 344.0 * kc["shaded_hits"]) / n_launch
+        stream_bytes = (32.0 + 24.0 * min(args.batch, len(frames))) * owned_px  # accumulation read+write per launch, G-buffer read per frame
+        alg_gather = gather_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        pt = ref.get("k_pathtrace_persistent", {}) if world == 1 else {}
+        src = ref.get("source")
+        roof = {"kernel": "k_pathtrace_persistent", "bound": "valu", "unit": "T lane-instr/s",
+                "peak": round(VALU_PEAK_TLANE, 2),
+                "peak_note": "f32 VALU spec: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (157.3 TFLOP/s / 2 flop per FMA)",
+                "avg_launch_ms": round(launch_ms, 4), "launches": kt["pathtrace"]["launches"],
+                "avg_primary_ms": round(kt["primary"]["ms"] / max(1, kt["primary"]["launches"]), 4),
+                "frames_per_launch": min(args.batch, len(frames)),
+                "alg_gather_GBps": round(alg_gather, 1), "alg_gather_bytes_per_launch": int(gather_bytes),
+                "alg_gather_served_by": "lds (the 8.4 KB scene is staged per workgroup; SURVEY 8d gather bytes never reach HBM)",
+                "alg_hbm_bytes_per_launch": int(stream_bytes),
+                "achieved": None, "frac": None, "traffic": None}
+        if pt.get("lane_instr_per_launch") and launch_ms > 0:
+            scale = min(args.batch, len(frames)) / float(pt.get("frames_per_launch", 32))
+            lane = pt["lane_instr_per_launch"] * scale
+            roof["achieved"] = round(lane / (launch_ms * 1e-3) / 1e12, 3)
+            roof["frac"] = round(roof["achieved"] / VALU_PEAK_TLANE, 4)
+            roof["lane_instr_per_launch"] = {"value": lane, "source": src}
+            for k in ("valu_lane_utilization", "valu_busy_frac", "effective_clock_GHz", "measured_issue_peak_Tlane"):
+                if k in pt:
+                    roof[k] = {"value": pt[k], "source": src}
+            if pt.get("hbm_bytes_per_launch"):
+                tb = pt["hbm_bytes_per_launch"] * scale
+                roof["traffic"] = tb
+                roof["traffic_source"] = src
+                roof["hbm_GBps"] = round(tb / (launch_ms * 1e-3) / 1e9, 1)
+                roof["hbm_frac"] = round(roof["hbm_GBps"] / HBM_PEAK_GBS, 4)
         out = {
             "metric": "Mrays/s (primary+secondary) at 1920x1080 SPP=64 depth=8",
-            "value": round(rays_total / elapsed / 1e6, 2),
+            "value": round(head["rays"] / head["elapsed"] / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -191,22 +304,38 @@ def main():
                                    "issued as batched dispatches of %d frames), depth 8, one present() per image" % args.batch,
                        "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
                        "parallelism": "%d-row stripes x %d ranks + 1 RCCL reduce/image" % (rtdist.STRIPE_ROWS, world) if world > 1 else "1 GPU",
-                       "frames_per_dispatch": args.batch, "rays_per_image": int(rays_total / args.steps)},
-            "roofline": {"bound": "hbm", "kernel": "k_pathtrace_persistent", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "avg_launch_ms": round(ktime["pathtrace_ms"], 4),
-                         "avg_primary_ms": round(ktime["primary_ms"], 4), "launches": ktime["launches"],
-                         "alg_bytes_per_launch": int(alg_bytes),
-                         "note": "algorithmic gather bytes (SURVEY 8d) are served by LDS/L1, so achieved can exceed the HBM "
-                                 "peak; the kernel is VALU-issue bound",
-                         "valu_busy_frac": pmc.get("valu_busy_frac"),
-                         "valu_lane_utilization": pmc.get("valu_lane_utilization"),
-                         "valu": pmc.get("valu")},
+                       "frames_per_dispatch": args.batch, "rays_per_image": int(head["rays"] / args.steps)},
+            "roofline": roof,
         }
+        cfgs = []
+        for name, scene, nframes, depth, m in extra:
+            kt, kc = m["ktimes"], m["kc"]
+            trace_ms = kt["wf_trace_shadow"]["ms"] + kt["wf_trace_ext"]["ms"]
+            trace_bytes = 32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"]    # per image (detailed pass = one image)
+            per_image_trace_ms = trace_ms / m["steps"]
+            entry = {"config": name, "workload": "%s 1920x1080, %d frames x depth %d, batches of %d" % (scene, nframes, depth, args.batch),
+                     "ms_per_image": round(m["elapsed"] / m["steps"] * 1e3, 2),
+                     "Mrays_s": round(m["rays"] / m["elapsed"] / 1e6, 1), "images": m["steps"],
+                     "kernel_ms_per_image": {k: round(v["ms"] / m["steps"], 3) for k, v in kt.items() if v["launches"]}}
+            if per_image_trace_ms > 0:
+                gbps = trace_bytes / (per_image_trace_ms * 1e-3) / 1e9
+                rk = ref.get("k_wf_trace", {}).get(scene, {}) if world == 1 else {}
+                entry["roofline"] = {"kernel": "k_wf_trace (any-hit + closest-hit launches)", "bound": "hbm",
+                                     "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gbps / HBM_PEAK_GBS, 4), "l2_peak": L2_PEAK_GBS,
+                                     "l2_frac": round(gbps / L2_PEAK_GBS, 4),
+                                     "alg_bytes_per_image": int(trace_bytes),
+                                     "served_by": "L1 / L2 / Infinity Cache (the scene, <= 40 MB, stays on die); "
+                                                  "algorithmic bytes = 32 B per node visit + 64 B per triangle test",
+                                     "traffic": rk.get("hbm_bytes_per_image"),
+                                     "traffic_source": ref.get("source") if rk else None}
+            cfgs.append(entry)
+        if cfgs:
+            out["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, bridge, frames)
+            out["cpu_baseline"] = cpu_baseline(pkg, head["bridge"], frames)
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -159,14 +159,36 @@ int rt_set_stripes(rt_ctx* ctx, uint32_t stripe_rows, uint32_t rank, uint32_t co
 void* rt_accum_device_ptr(rt_ctx* ctx);
 /* Use caller-owned device memory (width*height*16 bytes, same device) as the accumulation buffer,
  * e.g. a tensor the caller will hand to RCCL; NULL returns to the context's own buffer.
- * Call after rt_resize; the binding does not survive a later rt_resize of a different size. */
+ * Call after rt_resize; a later rt_resize drops the binding and compute() / present() fail until it is renewed. */
 int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
+/* present() reads this caller-owned float4 buffer (width*height*16 bytes, same device) instead of the accumulation
+ * buffer; NULL returns to the accumulation buffer.  The sharded renderer reduces the ranks' stripe accumulators into
+ * such a display buffer, so the per-rank accumulators stay disjoint and a progressive render can go on after a
+ * gather.  Like rt_bind_accum, the binding is dropped by rt_resize, and compute() / present() then fail with
+ * RT_ERR_INVALID until the caller binds again (either call, NULL included, acknowledges the new size). */
+int rt_bind_present_source(rt_ctx* ctx, void* device_ptr);
 /* Run every subsequent enqueue on a caller-provided hipStream_t (NULL = context's own stream). */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Average duration in ms of the path-trace kernel over the launches since the last call
  * (HIP events recorded on the context stream around each launch); also returns the launch count. */
 int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
 int rt_set_kernel_timing(rt_ctx* ctx, int enabled);
+/* Per-kernel timers (HIP events on the context stream around every launch while timing is enabled): sum of the
+ * durations in ms and launch count per RT_TIMER_* since the last read; n = number of entries the arrays hold. */
+enum {
+  RT_TIMER_PRIMARY = 0,         /* k_primary_visibility                                                    */
+  RT_TIMER_PATHTRACE = 1,       /* k_pathtrace_persistent, or one whole wavefront dispatch (all depths)    */
+  RT_TIMER_WF_SHADE = 2,        /* k_wf_shade, one entry per depth                                         */
+  RT_TIMER_WF_TRACE_SHADOW = 3, /* k_wf_trace<any hit>                                                     */
+  RT_TIMER_WF_TRACE_EXT = 4,    /* k_wf_trace<closest hit>                                                 */
+  RT_TIMER_POST = 5,            /* k_postprocess                                                           */
+  RT_TIMER_COUNT = 6
+};
+int rt_kernel_times(rt_ctx* ctx, double* sum_ms, uint32_t* launches, uint32_t n);
+/* Diagnostic build (-DRT_CLOCK_STAMP) only: {delta s_memtime, delta s_memrealtime} of each workgroup of the last
+ * k_pathtrace_persistent launch (in-kernel clock = ratio x 100 MHz).  Returns the number of pairs written, 0 in the
+ * product build, where no stamp executes. */
+int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
 /* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
  *   3 = auto (default): wavefront form when the scene's records do not fit LDS, SPP == 1 and the dispatch carries
  *       >= 4 frames (rt_compute_batch); the persistent kernel otherwise

@@ -16,14 +16,22 @@
 //   src/renderer/ResourceManager.ts:348-447          -> section "uniforms"
 //   src/renderer/WebGPURenderer.ts:88-129            -> compute()/present()
 // The numeric meaning of every WGSL builtin is fixed by include/mi355rt_math.h.
-// Build: g++ -O2 -ffp-contract=off (see oracle/Makefile).  Scalar code, rows of
-// the image distributed over std::thread workers (the timed CPU baseline).
+// Build: g++ -O2 -ffp-contract=off (see oracle/Makefile).  Scalar code, 128-pixel
+// spans of the owned rows distributed over a persistent pool of std::thread workers
+// (the timed CPU baseline).
 
 #include "../include/mi355rt_layout.h"
 #include "../include/mi355rt_math.h"
 
+#include <sched.h>
+
 #include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -903,28 +911,122 @@ struct Oracle {
   std::vector<uint8_t> post_out;  // staged, then copied to render_target (output texture)
 
   // -------------------------------------------------------------- driver
+  // Work items are 128-pixel spans of the rows this renderer owns (a 1080p third is 5 400 items, so a few hundred
+  // threads stay balanced); every item counts into a Counters on the worker's stack and is folded into the thread's
+  // own cache line once per item (per-thread slots used to sit 48 B apart and were bumped on every node visit:
+  // false sharing).  The workers are a persistent pool (WorkerPool below), not threads spawned per pass.
+  struct alignas(128) PaddedCounters {
+    Counters c;
+  };
+  static const uint32_t SPAN = 128;
   template <class F>
-  void parallel_rows(F&& fn) {
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  void parallel_spans(bool owned_only, F&& fn) {
+    std::vector<uint32_t> rows;
+    rows.reserve(height);
+    for (uint32_t y = 0; y < height; y++)
+      if (!owned_only || owns_row(y)) rows.push_back(y);
+    const uint32_t spans_per_row = (width + SPAN - 1) / SPAN;
+    const uint32_t n_items = (uint32_t)rows.size() * spans_per_row;
+    int nt = threads > 0 ? threads : usable_threads();
     if (nt < 1) nt = 1;
+    if ((uint32_t)nt > n_items) nt = n_items ? (int)n_items : 1;
+    std::vector<PaddedCounters> local((size_t)nt);
     std::atomic<uint32_t> next{0};
-    std::vector<Counters> local((size_t)nt);
     auto worker = [&](int tid) {
       for (;;) {
-        uint32_t y = next.fetch_add(1);
-        if (y >= height) break;
-        fn(y, local[(size_t)tid]);
+        const uint32_t it = next.fetch_add(1, std::memory_order_relaxed);
+        if (it >= n_items) break;
+        const uint32_t y = rows[it / spans_per_row], x0 = (it % spans_per_row) * SPAN;
+        const uint32_t x1 = x0 + SPAN < width ? x0 + SPAN : width;
+        Counters item;
+        fn(y, x0, x1, item);
+        local[(size_t)tid].c.add(item);
       }
     };
-    if (nt == 1) {
-      worker(0);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nt; t++) pool.emplace_back(worker, t);
-      for (auto& th : pool) th.join();
-    }
-    for (auto& l : local) counters.add(l);
+    pool.run(nt, worker);
+    for (auto& l : local) counters.add(l.c);
   }
+
+  // threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota when one is set
+  static int usable_threads() {
+    int n = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = (int)std::thread::hardware_concurrency();
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+      char q[64];
+      long long period = 0;
+      if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+        const long long quota = atoll(q);
+        const int cap = (int)((quota + period - 1) / period);
+        if (cap >= 1 && cap < n) n = cap;
+      }
+      fclose(f);
+    }
+    return n < 1 ? 1 : n;
+  }
+
+  // Persistent worker pool: threads are created once (and again only when more are asked for) and parked on a
+  // condition variable between passes; the calling thread works as worker 0.
+  struct WorkerPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int active = 0, pending = 0;
+    bool quit = false;
+    void loop(int tid) {
+      uint64_t seen = 0;
+      for (;;) {
+        std::function<void(int)> j;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv_start.wait(lk, [&] { return quit || (generation != seen && tid < active); });
+          if (quit) return;
+          seen = generation;
+          j = job;
+        }
+        j(tid);
+        {
+          std::lock_guard<std::mutex> lk(m);
+          if (--pending == 0) cv_done.notify_one();
+        }
+      }
+    }
+    template <class W>
+    void run(int nt, W& worker) {
+      if (nt <= 1) {
+        worker(0);
+        return;
+      }
+      while ((int)threads.size() < nt - 1) {
+        const int tid = (int)threads.size() + 1;
+        threads.emplace_back([this, tid] { loop(tid); });
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        job = [&worker](int tid) { worker(tid); };
+        active = nt;
+        pending = nt - 1;
+        generation++;
+      }
+      cv_start.notify_all();
+      worker(0);
+      std::unique_lock<std::mutex> lk(m);
+      cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~WorkerPool() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        quit = true;
+      }
+      cv_start.notify_all();
+      for (auto& t : threads) t.join();
+    }
+  };
+  WorkerPool pool;
 
   // ----------------------------------------------------------- uniforms
   static double halton(uint32_t index, uint32_t base) {  // ResourceManager.ts:348-357
@@ -979,7 +1081,7 @@ struct oracle_ctx {
 oracle_ctx* oracle_create(void) { return new oracle_ctx(); }
 void oracle_destroy(oracle_ctx* c) { delete c; }
 void oracle_set_threads(oracle_ctx* c, int n) { c->o.threads = n; }
-int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
+int oracle_hardware_threads(void) { return Oracle::usable_threads(); }  // affinity mask and cgroup quota respected
 
 void oracle_build_pipeline(oracle_ctx* c, uint32_t depth, uint32_t spp) {
   c->o.max_depth = depth;
@@ -1075,21 +1177,19 @@ void oracle_compute(oracle_ctx* c, uint32_t frame_count) {
   o.step_jitter(o.total_frames, frame_count);  // updateFrameUniforms: Halton index from totalFrames
   o.write_mixed(frame_count);
   if (o.nodes.empty() || o.topology.empty() || o.instances.empty() || o.width == 0) return;
-  o.parallel_rows([&](uint32_t y, Counters& cn) {
-    if (!o.owns_row(y)) return;
-    for (uint32_t x = 0; x < o.width; x++) o.gbuffer_pixel(x, y, cn);
+  o.parallel_spans(true, [&](uint32_t y, uint32_t x0, uint32_t x1, Counters& cn) {
+    for (uint32_t x = x0; x < x1; x++) o.gbuffer_pixel(x, y, cn);
   });
-  o.parallel_rows([&](uint32_t y, Counters& cn) {
-    if (!o.owns_row(y)) return;
-    for (uint32_t x = 0; x < o.width; x++) o.trace_pixel(x, y, cn);
+  o.parallel_spans(true, [&](uint32_t y, uint32_t x0, uint32_t x1, Counters& cn) {
+    for (uint32_t x = x0; x < x1; x++) o.trace_pixel(x, y, cn);
   });
 }
 // WebGPURenderer.present (WebGPURenderer.ts:104-129)
 void oracle_present(oracle_ctx* c) {
   Oracle& o = c->o;
   if (o.width == 0) return;
-  o.parallel_rows([&](uint32_t y, Counters&) {
-    for (uint32_t x = 0; x < o.width; x++) o.post_pixel(x, y);
+  o.parallel_spans(false, [&](uint32_t y, uint32_t x0, uint32_t x1, Counters&) {
+    for (uint32_t x = x0; x < x1; x++) o.post_pixel(x, y);
   });
   o.render_target = o.post_out;
   o.history_index = 1 - o.history_index;

@@ -218,25 +218,95 @@ def test_reupload_larger_scene_and_resize(W, oracle_lib, gpu_renderer):
     pu.assert_parity(gpu_renderer, cpu, check_output=True)
 
 
-@pytest.mark.parametrize("scene,depth", [("instanced1000", 8), ("sponza_like", 8), ("glass_blob", 16)])
-def test_full_size_oracle_band(W, oracle_lib, gpu_renderer, scene, depth):
-    """BASELINE configs 3-5 at full resolution: the GPU renders the whole frame, the oracle only one 8-row band;
-    the band must agree bit for bit, the frame must be finite with the right sample count."""
-    b = pu.bridge_for(W, scene)
-    w, h = (1920, 1080) if scene != "glass_blob" else (3840, 2160)
-    frames = (1, 2)
-    pu.drive(gpu_renderer, W, b, w, h, depth, 1, frames, present=False, detailed=False)
+def _band_rows(h, div):
+    return (np.arange(h) // 8) % div == 0
+
+
+def test_bench_workload_parity_1080p(W, oracle_lib, gpu_renderer):
+    """Exactly what bench.py times — Cornell 1920x1080, depth 8, computeBatch(1..32), computeBatch(33..64), present() —
+    against the oracle on the 8-row bands (y // 8) % 27 == 0 of the same 64 frames: accumulation band bit for bit, the
+    RGBA8 rows whose post-pass footprint (2-pixel halo) lies inside a band, and all six counters of a second, band-only
+    GPU pass with the detailed-counter kernel variant."""
+    b = pu.bridge_for(W, "cornell")
+    w, h, depth, div = 1920, 1080, 8, 27
+    frames = list(range(1, 65))
+    gpu_renderer.buildPipeline(depth, 1)
+    W.upload_scene(gpu_renderer, b, w, h)
+    gpu_renderer.resetCounters()
+    gpu_renderer.computeBatch(frames[:32])
+    gpu_renderer.computeBatch(frames[32:])
+    gpu_renderer.present()
+    gpu_renderer.sync()
     acc = gpu_renderer.readAccum()
-    assert np.isfinite(acc).all() and (acc[..., 3] == len(frames)).all()
+    rgba = gpu_renderer.captureFrame()["data"].copy()
     c = gpu_renderer.getCounters()
-    assert c["primary_rays"] == w * h * len(frames)
-    stripes = h // 8
-    band = stripes // 2
+    assert np.isfinite(acc).all() and (acc[..., 3] == 64.0).all()
+    assert c["primary_rays"] == w * h * 64
+
     cpu = oracle_lib.OracleRenderer()
-    cpu.setStripes(8, band, stripes)
-    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
-    rows = slice(band * 8, band * 8 + 8)
-    assert np.array_equal(cpu.readAccum()[rows].view(np.uint32), acc[rows].view(np.uint32))
+    cpu.buildPipeline(depth, 1)
+    W.upload_scene(cpu, b, w, h)
+    cpu.setStripes(8, 0, div)
+    cpu.resetCounters()
+    for f in frames:
+        cpu.compute(f)
+    rows = _band_rows(h, div)
+    assert int(rows.sum()) == 40
+    cacc = cpu.readAccum()
+    assert np.array_equal(cacc[rows].view(np.uint32), acc[rows].view(np.uint32)), \
+        pu.describe_mismatch("accumulation band", acc[rows], cacc[rows])
+    assert np.array_equal(gpu_renderer.readUniforms(), cpu.readUniforms())
+    cpu.present()    # rows 2..5 of every band only read accumulation texels of that band (5x5 footprint)
+    inner = rows & (np.arange(h) % 8 >= 2) & (np.arange(h) % 8 <= 5)
+    crgba = cpu.captureFrame()["data"]
+    assert np.array_equal(crgba[inner], rgba[inner]), pu.describe_mismatch("RGBA8 band interior", rgba[inner], crgba[inner])
+
+    band = W.WebGPURenderer(0)          # same 64 frames, the band only, detailed counters: equals the oracle's counts
+    band.buildPipeline(depth, 1)
+    W.upload_scene(band, b, w, h)
+    band.setStripes(8, 0, div)
+    band.setCounting(True)
+    band.resetCounters()
+    band.computeBatch(frames[:32])
+    band.computeBatch(frames[32:])
+    band.sync()
+    assert band.getCounters() == cpu.getCounters()
+    assert np.array_equal(band.readAccum()[rows].view(np.uint32), cacc[rows].view(np.uint32))
+    band.destroy()
+
+
+@pytest.mark.parametrize("scene,w,h,depth,nframes,batch,div", [
+    ("viewer_diamond", 1280, 720, 8, 16, 16, 9),     # config 2 at its BASELINE size and frame count (persistent kernel)
+    ("instanced1000", 1920, 1080, 8, 8, 8, 135),     # config 3, full size, 8 of its 64 frames as one batch (wavefront form)
+    ("sponza_like", 1920, 1080, 8, 8, 8, 135),       # config 4
+    ("glass_blob", 3840, 2160, 16, 8, 8, 270),       # config 5 at 4K, depth 16
+])
+def test_full_size_oracle_band(W, oracle_lib, gpu_renderer, scene, w, h, depth, nframes, batch, div):
+    """BASELINE configs 2-5 at full resolution through the batched dispatch the benchmark uses (auto kernel form: the
+    wavefront form for configs 3-5): the GPU renders whole frames, the oracle the 8-row bands (y // 8) % div == 0; the
+    bands must agree bit for bit, the frames must be finite with the right sample count."""
+    b = pu.bridge_for(W, scene)
+    frames = list(range(1, nframes + 1))
+    gpu_renderer.buildPipeline(depth, 1)
+    W.upload_scene(gpu_renderer, b, w, h)
+    gpu_renderer.resetCounters()
+    for i in range(0, nframes, batch):
+        gpu_renderer.computeBatch(frames[i:i + batch])
+    gpu_renderer.sync()
+    acc = gpu_renderer.readAccum()
+    assert np.isfinite(acc).all() and (acc[..., 3] == nframes).all()
+    c = gpu_renderer.getCounters()
+    assert c["primary_rays"] == w * h * nframes
+    cpu = oracle_lib.OracleRenderer()
+    cpu.buildPipeline(depth, 1)
+    W.upload_scene(cpu, b, w, h)
+    cpu.setStripes(8, 0, div)
+    for f in frames:
+        cpu.compute(f)
+    rows = _band_rows(h, div)
+    cacc = cpu.readAccum()
+    assert np.array_equal(cacc[rows].view(np.uint32), acc[rows].view(np.uint32)), \
+        pu.describe_mismatch("accumulation band", acc[rows], cacc[rows])
 
 
 @pytest.mark.parametrize("scene,w,h,depth,spp,frames,batch", [

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_path, w, h, frames, stripe_rows):
+def _worker(rank, world, port, out_path, w, h, frames, more_frames, stripe_rows):
     for p in (REPO, os.path.join(REPO, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,9 +42,17 @@ def _worker(rank, world, port, out_path, w, h, frames, stripe_rows):
         assert not local[~rows].any(), "rank wrote outside its stripes"
         assert local[rows][..., 3].min() == len(frames)
         shard.gather(present=True)
+        # the gather leaves the stripe accumulators alone (out-of-place reduce) ...
+        assert np.array_equal(r.readAccum().view(np.uint32), local.view(np.uint32))
         if rank == 0:
-            np.save(out_path, r.readAccum())
+            np.save(out_path, shard.read_image())
             np.save(out_path + ".rgba.npy", r.captureFrame()["data"])
+        # ... so the progressive render goes on and a second gather is the single-process image of that moment
+        shard.render(more_frames)
+        shard.gather(present=True)
+        if rank == 0:
+            np.save(out_path + ".more.npy", shard.read_image())
+            np.save(out_path + ".more.rgba.npy", r.captureFrame()["data"])
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -53,9 +61,9 @@ def _worker(rank, world, port, out_path, w, h, frames, stripe_rows):
 @pytest.mark.parametrize("world,stripe_rows,h", [(2, 16, 72), (3, 8, 50)])
 def test_two_rank_stripes_reduce_to_the_single_process_image(W, oracle_lib, tmp_path, world, stripe_rows, h):
     import torch.multiprocessing as mp
-    w, frames = 64, (1, 2, 3)
+    w, frames, more_frames = 64, (1, 2, 3), (4, 5)
     out = str(tmp_path / "acc.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out, w, h, frames, stripe_rows), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, w, h, frames, more_frames, stripe_rows), nprocs=world, join=True)
     sharded = np.load(out)
     rgba = np.load(out + ".rgba.npy")
 
@@ -69,6 +77,12 @@ def test_two_rank_stripes_reduce_to_the_single_process_image(W, oracle_lib, tmp_
     assert np.array_equal(sharded.view(np.uint32), ref.readAccum().view(np.uint32))
     ref.present()
     assert np.array_equal(rgba, ref.captureFrame()["data"])
+    # render -> gather -> render -> gather (the live loop's present-every-frame pattern across ranks)
+    for f in more_frames:
+        ref.compute(f)
+    assert np.array_equal(np.load(out + ".more.npy").view(np.uint32), ref.readAccum().view(np.uint32))
+    ref.present()
+    assert np.array_equal(np.load(out + ".more.rgba.npy"), ref.captureFrame()["data"])
 
 
 def test_owned_rows_partition_the_image():

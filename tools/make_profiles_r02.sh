@@ -1,0 +1,45 @@
+#!/bin/bash
+# rocprofv3 evidence of round 2 (run on the GPU box via gpurun; HEAD=<commit> in the environment names the code state).
+# usage: bash tools/make_profiles_r02.sh [cornell|big|all]
+R=$GRAFT_REPO_ROOT
+WHAT=${1:-all}
+OUT=$R/gpurun_out/profiles_r02
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+pmc_pass() {  # name scene frames depth batch images counters...
+  local name=$1 scene=$2 frames=$3 depth=$4 batch=$5 images=$6; shift 6
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$scene/$name -- python3 $R/tools/prof_workload.py $scene $frames $depth $batch $images > $OUT/pmc_${scene}_$name.log 2>&1 || { echo "pass failed: $scene $name"; tail -3 $OUT/pmc_${scene}_$name.log; }
+}
+if [ "$WHAT" = cornell ] || [ "$WHAT" = all ]; then
+  # 1. kernel trace + stats of the bench command itself
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/r02_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+  grep -c '"metric"' $OUT/r02_bench_under_rocprof.json || tail -5 $OUT/bench_under_rocprof.err
+  cp $OUT/bench_trace/*/*_kernel_stats.csv $OUT/r02_bench_kernel_stats.csv
+  rm -rf $OUT/bench_trace
+  # 2. PMC passes, each in its own run: 2 images = 4 path-trace launches of 32 frames
+  rm -rf $OUT/pmc_cornell
+  pmc_pass sq1 cornell 64 8 32 2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
+  pmc_pass sq2 cornell 64 8 32 2 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES SQ_LDS_BANK_CONFLICT
+  pmc_pass fetch cornell 64 8 32 2 FETCH_SIZE
+  pmc_pass write cornell 64 8 32 2 WRITE_SIZE
+  pmc_pass grbm cornell 64 8 32 2 GRBM_GUI_ACTIVE
+  python3 $R/tools/pmc_collect.py $OUT/pmc_cornell $OUT/r02_cornell_pmc.json > /dev/null
+fi
+if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
+  for scene in sponza_like instanced1000; do
+    rm -rf $OUT/pmc_$scene
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$scene -- python3 $R/tools/prof_workload.py $scene 64 8 32 1 > $OUT/trace_$scene.log 2>&1
+    cp $OUT/trace_$scene/*/*_kernel_stats.csv $OUT/r02_${scene}_kernel_stats.csv
+    rm -rf $OUT/trace_$scene
+    pmc_pass sq1 $scene 32 8 32 1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
+    pmc_pass tcp1 $scene 32 8 32 1 TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+    pmc_pass tcp2 $scene 32 8 32 1 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
+    pmc_pass tcp3 $scene 32 8 32 1 TCP_GATE_EN1_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum
+    pmc_pass tcc1 $scene 32 8 32 1 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+    pmc_pass fetch $scene 32 8 32 1 FETCH_SIZE
+    pmc_pass write $scene 32 8 32 1 WRITE_SIZE
+    pmc_pass grbm $scene 32 8 32 1 GRBM_GUI_ACTIVE
+    python3 $R/tools/pmc_collect.py $OUT/pmc_$scene $OUT/r02_${scene}_pmc.json > /dev/null
+  done
+fi
+ls $OUT

@@ -582,6 +582,12 @@ __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_t
          ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
 }
 
+// Diagnostic build only (-DRT_CLOCK_STAMP, tools/clock_check.py): every workgroup of the persistent kernel stamps
+// s_memtime / s_memrealtime around its work loop into this array, which nothing else reads; the in-kernel clock is
+// delta(memtime) / delta(memrealtime) x 100 MHz.  In the product build no stamp executes.
+#define RT_CLOCK_STAMP_SLOTS 4096
+__device__ unsigned long long g_clock_stamps[2 * RT_CLOCK_STAMP_SLOTS];
+
 // Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
 // is latency bound and gains ~11 % from 6 waves/SIMD even with the spills that costs (measured on MI355X).
 template <bool DETAIL, bool LDS>
@@ -641,6 +647,9 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
   }
 
+#ifdef RT_CLOCK_STAMP
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (U.width + 7u) / 8u;
   // tickets enumerate only the tile rows this rank owns when the stripes are tile-aligned
@@ -835,6 +844,12 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     if (!work_left && __ballot(alive || have_pixel) == 0ull) break;
   }
 
+#ifdef RT_CLOCK_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < RT_CLOCK_STAMP_SLOTS) {
+    g_clock_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    g_clock_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
   // counters: one flush per persistent wave
   LaneCounters c;
   c.primary = 0;

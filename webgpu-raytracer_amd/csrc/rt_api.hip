@@ -62,6 +62,8 @@ struct rt_ctx {
   uint32_t width = 0, height = 0;
   DeviceBuffer accum, render_target, g_normal, g_depth, history[2], counters;
   void* external_accum = nullptr;
+  void* present_source = nullptr;   // rt_bind_present_source: present() reads this instead of the accumulation buffer
+  bool external_stale = false;      // a bound buffer was sized for the screen before the last rt_resize
   int history_index = 0;
 
   // uniforms + host state (ResourceManager fields)
@@ -84,6 +86,13 @@ struct rt_ctx {
   size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
+  // pinned staging ring for the slot tables: the H2D copy of a dispatch's table is truly asynchronous and its source
+  // outlives it (entry k is reused only after the event recorded behind its copy has completed)
+  static constexpr int kSlotRing = 8;
+  DevFrameSlot* slot_ring = nullptr;   // kSlotRing x 64 slots, hipHostMalloc
+  hipEvent_t slot_ring_ev[kSlotRing] = {};
+  bool slot_ring_used[kSlotRing] = {};
+  int slot_ring_next = 0;
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
   DeviceBuffer frame_col;   // per-frame colours of a batch, added in frame order by k_accumulate_frames
   DeviceBuffer wf_state, wf_queues, wf_counters;  // wavefront form: path state, ray / path queues, queue counters
@@ -92,7 +101,7 @@ struct rt_ctx {
   bool timing = false;
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
-  std::vector<std::pair<size_t, int>> ev_tags;  // (pool index, 0 = primary, 1 = pathtrace)
+  std::vector<std::pair<size_t, int>> ev_tags;  // (pool index, RT_TIMER_* of mi355rt.h)
 
   rt_ctx() {
     std::memset(&uniforms, 0, sizeof(uniforms));
@@ -381,6 +390,9 @@ void rt_destroy(rt_ctx* c) {
     (void)hipEventDestroy(p.b);
   }
   if (c->bv_pinned) (void)hipHostFree(c->bv_pinned);
+  if (c->slot_ring) (void)hipHostFree(c->slot_ring);
+  for (int k = 0; k < rt_ctx::kSlotRing; k++)
+    if (c->slot_ring_ev[k]) (void)hipEventDestroy(c->slot_ring_ev[k]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -418,7 +430,12 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   }
   c->width = width;
   c->height = height;
-  c->external_accum = nullptr;  // a bound accumulation buffer belongs to the old size
+  // A bound accumulation / present buffer was sized for the old screen: it is dropped, and until the caller binds
+  // again (rt_bind_accum / rt_bind_present_source, NULL included) compute() and present() refuse to run instead of
+  // silently rendering into the internal buffer while the caller keeps reducing its stale one.
+  if (c->external_accum || c->present_source) c->external_stale = true;
+  c->external_accum = nullptr;
+  c->present_source = nullptr;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RT_OK;
 }
@@ -816,9 +833,11 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   }
   uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
   const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * 16);
-  EventPair* ev = next_events(c, 1);
+  EventPair* ev = next_events(c, RT_TIMER_PATHTRACE);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   for (uint32_t depth = 0; depth < depths; depth++) {
+    EventPair* evs = next_events(c, RT_TIMER_WF_SHADE);
+    if (evs) HIP_TRY(c, hipEventRecord(evs->a, c->stream));
     if (depth == 0) {
       if (detail)
         hipLaunchKernelGGL((rtk::k_wf_shade<true, true>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
@@ -830,6 +849,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       else
         hipLaunchKernelGGL((rtk::k_wf_shade<false, false>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
     }
+    if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
     for (int k = 0; k < 2; k++) {
       uint32_t blocks = (uint32_t)c->wf_occ_blocks[k] * (uint32_t)c->num_cus;
       const uint32_t max_useful = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)0x7fffffff);
@@ -838,7 +858,10 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       DevFrame Fa = F;
       rt_scene_uniforms Ua = c->uniforms;
       void* args[] = {&Sa, &Fa, &Ua, &W, &Q, &depth, &nn, &nt, &ni};
+      EventPair* evt = next_events(c, k == 0 ? RT_TIMER_WF_TRACE_SHADOW : RT_TIMER_WF_TRACE_EXT);
+      if (evt) HIP_TRY(c, hipEventRecord(evt->a, c->stream));
       HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(256), args, dyn, c->stream));
+      if (evt) HIP_TRY(c, hipEventRecord(evt->b, c->stream));
     }
   }
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
@@ -864,6 +887,8 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     slots[i].pad2 = 0;
   }
   if (!scene_ready(c)) return RT_SKIPPED;
+  if (c->external_stale)
+    return fail(c, RT_ERR_INVALID, "the bound accumulation buffer was dropped by rt_resize: call rt_bind_accum again");
   HIP_TRY(c, hipSetDevice(c->device));
   // Host-side shape checks before any kernel indexes these buffers.
   if (c->uniforms.light_count > c->n_lights)
@@ -899,12 +924,22 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
       slots[i].depth = (float*)(base + npx * 20);
     }
   }
-  r = ensure_buffer(c, c->slots, (size_t)n * sizeof(DevFrameSlot), true);
+  // The table goes through a pinned ring, one device table per ring entry: the copy is asynchronous, its source
+  // outlives it, and a dispatch still in flight keeps reading its own table while the next one is being written.
+  if (!c->slot_ring) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->slot_ring, (size_t)rt_ctx::kSlotRing * 64 * sizeof(DevFrameSlot), hipHostMallocDefault));
+    for (int k = 0; k < rt_ctx::kSlotRing; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ring_ev[k], hipEventDisableTiming));
+  }
+  r = ensure_buffer(c, c->slots, (size_t)rt_ctx::kSlotRing * 64 * sizeof(DevFrameSlot), false);
   if (r < 0) return r;
-  // pageable source: the runtime stages the bytes before returning, so `slots` may go out of scope
-  HIP_TRY(c, hipMemcpyAsync(c->slots.ptr, slots.data(), (size_t)n * sizeof(DevFrameSlot), hipMemcpyHostToDevice,
-                            c->stream));
-  const DevFrameSlot* dslots = (const DevFrameSlot*)c->slots.ptr;
+  const int ring = c->slot_ring_next;
+  c->slot_ring_next = (ring + 1) % rt_ctx::kSlotRing;
+  if (c->slot_ring_used[ring]) HIP_TRY(c, hipEventSynchronize(c->slot_ring_ev[ring]));  // the dispatch that used this entry is done
+  DevFrameSlot* host_slots = c->slot_ring + (size_t)ring * 64;
+  std::memcpy(host_slots, slots.data(), (size_t)n * sizeof(DevFrameSlot));
+  DevFrameSlot* dev_slots = (DevFrameSlot*)c->slots.ptr + (size_t)ring * 64;
+  HIP_TRY(c, hipMemcpyAsync(dev_slots, host_slots, (size_t)n * sizeof(DevFrameSlot), hipMemcpyHostToDevice, c->stream));
+  const DevFrameSlot* dslots = dev_slots;
 
   DevScene S = dev_scene(c);
   DevFrame F;
@@ -936,7 +971,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   const uint32_t ptiles = F.own_period ? ((c->width + 7) / 8) * F.own_tile_rows : tiles;  // primary kernel grid
 
   // 1. primary visibility (the reference clears + rasterises the G-buffer every compute()); frame = blockIdx.y
-  EventPair* ev = next_events(c, 0);
+  EventPair* ev = next_events(c, RT_TIMER_PRIMARY);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   {
     const size_t plds = rtk::primary_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts) * 16;
@@ -960,7 +995,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     r = launch_wavefront(c, S, F, dslots, n, fits_lds);
     if (r < 0) return r;
   } else if (c->variant == 0) {
-    ev = next_events(c, 1);
+    ev = next_events(c, RT_TIMER_PATHTRACE);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     if (c->detailed_counters)
       hipLaunchKernelGGL(rtk::k_pathtrace<true>, dim3(tiles), dim3(64), 0, c->stream, S, F, c->uniforms);
@@ -994,7 +1029,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
     uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts, ns = n;
     void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv, &dslots, &ns};
-    ev = next_events(c, 1);
+    ev = next_events(c, RT_TIMER_PATHTRACE);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
     if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
@@ -1003,6 +1038,8 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
                          n, c->width, c->height);
   }
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->slot_ring_ev[ring], c->stream));
+  c->slot_ring_used[ring] = true;
   return RT_OK;
 }
 
@@ -1017,14 +1054,19 @@ int rt_compute_batch(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
 int rt_present(rt_ctx* c) {
   if (!c) return RT_ERR_INVALID;
   if (!c->width || !c->render_target.ptr || !c->accum.ptr) return RT_SKIPPED;  // PostProcessPass.ts:32-38
+  if (c->external_stale)
+    return fail(c, RT_ERR_INVALID, "the bound accumulation buffer was dropped by rt_resize: call rt_bind_accum again");
   HIP_TRY(c, hipSetDevice(c->device));
   DevPost P;
-  P.accum = accum_ptr(c);
+  P.accum = c->present_source ? (const float4*)c->present_source : accum_ptr(c);
   P.history_in = (const ushort4*)c->history[1 - c->history_index].ptr;  // previous frame (read)
   P.history_out = (ushort4*)c->history[c->history_index].ptr;           // current frame (write)
   P.out_rgba8 = (uint32_t*)c->render_target.ptr;
   dim3 grid((c->width + 15) / 16, (c->height + 15) / 16);
+  EventPair* ev = next_events(c, RT_TIMER_POST);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   hipLaunchKernelGGL(rtk::k_postprocess, grid, dim3(256), 0, c->stream, P, c->uniforms);
+  if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
   HIP_TRY(c, hipGetLastError());
   c->history_index = 1 - c->history_index;  // swap history index for TAA
   return RT_OK;
@@ -1144,6 +1186,15 @@ int rt_bind_accum(rt_ctx* c, void* device_ptr) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->external_accum = device_ptr;
+  c->external_stale = false;
+  return RT_OK;
+}
+int rt_bind_present_source(rt_ctx* c, void* device_ptr) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->present_source = device_ptr;
+  c->external_stale = false;
   return RT_OK;
 }
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
@@ -1163,24 +1214,45 @@ int rt_set_kernel_timing(rt_ctx* c, int enabled) {
   c->timing = enabled != 0;
   return RT_OK;
 }
-int rt_kernel_time_ms(rt_ctx* c, double* avg_pt, double* avg_pv, uint32_t* launches) {
-  if (!c) return RT_ERR_INVALID;
+int rt_debug_clock_stamps(rt_ctx* c, uint64_t* out_pairs, uint32_t cap_pairs) {
+  if (!c || !out_pairs) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  double sum[2] = {0, 0};
-  uint32_t cnt[2] = {0, 0};
+  const uint32_t n = cap_pairs < RT_CLOCK_STAMP_SLOTS ? cap_pairs : RT_CLOCK_STAMP_SLOTS;
+  HIP_TRY(c, hipMemcpyFromSymbol(out_pairs, HIP_SYMBOL(rtk::g_clock_stamps), (size_t)n * 16, 0, hipMemcpyDeviceToHost));
+#ifdef RT_CLOCK_STAMP
+  return (int)n;
+#else
+  return 0;  // product build: the kernels execute no stamp
+#endif
+}
+int rt_kernel_times(rt_ctx* c, double* sum_ms, uint32_t* launches, uint32_t n) {
+  if (!c || !sum_ms || !launches) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t k = 0; k < n; k++) {
+    sum_ms[k] = 0.0;
+    launches[k] = 0;
+  }
   for (auto& t : c->ev_tags) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev_pool[t.first].a, c->ev_pool[t.first].b) == hipSuccess) {
-      sum[t.second] += ms;
-      cnt[t.second]++;
+    if ((uint32_t)t.second < n && hipEventElapsedTime(&ms, c->ev_pool[t.first].a, c->ev_pool[t.first].b) == hipSuccess) {
+      sum_ms[t.second] += ms;
+      launches[t.second]++;
     }
   }
-  if (avg_pv) *avg_pv = cnt[0] ? sum[0] / cnt[0] : 0.0;
-  if (avg_pt) *avg_pt = cnt[1] ? sum[1] / cnt[1] : 0.0;
-  if (launches) *launches = cnt[1];
   c->ev_tags.clear();
   c->ev_used = 0;
+  return RT_OK;
+}
+int rt_kernel_time_ms(rt_ctx* c, double* avg_pt, double* avg_pv, uint32_t* launches) {
+  double sum[RT_TIMER_COUNT];
+  uint32_t cnt[RT_TIMER_COUNT];
+  int r = rt_kernel_times(c, sum, cnt, RT_TIMER_COUNT);
+  if (r < 0) return r;
+  if (avg_pv) *avg_pv = cnt[RT_TIMER_PRIMARY] ? sum[RT_TIMER_PRIMARY] / cnt[RT_TIMER_PRIMARY] : 0.0;
+  if (avg_pt) *avg_pt = cnt[RT_TIMER_PATHTRACE] ? sum[RT_TIMER_PATHTRACE] / cnt[RT_TIMER_PATHTRACE] : 0.0;
+  if (launches) *launches = cnt[RT_TIMER_PATHTRACE];
   return RT_OK;
 }
 

@@ -54,7 +54,9 @@ def load_library(path=None):
         "rt_get_kernel_counters": (i32, [vp, i32, vp]), "rt_bind_accum": (i32, [vp, vp]),
         "rt_reset_counters": (i32, [vp]), "rt_set_counting": (i32, [vp, i32]),
         "rt_set_stripes": (i32, [vp, u32, u32, u32]), "rt_accum_device_ptr": (vp, [vp]),
-        "rt_set_stream": (i32, [vp, vp]),
+        "rt_set_stream": (i32, [vp, vp]), "rt_bind_present_source": (i32, [vp, vp]),
+        "rt_debug_clock_stamps": (i32, [vp, vp, u32]),
+        "rt_kernel_times": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32), u32]),
         "rt_kernel_time_ms": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(u32)]),
         "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
@@ -74,7 +76,7 @@ EXPORTED_SYMBOLS = (
     "rt_alloc_texture_layers rt_upload_texture_image rt_read_texture_layer rt_build_blas "
     "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_compute_batch rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
-    "rt_get_kernel_counters rt_bind_accum "
+    "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count rt_set_kernel_variant").split()
 
@@ -267,7 +269,11 @@ class WebGPURenderer:
         return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
 
     def bindAccum(self, device_ptr):
-        self._check(self.L.rt_bind_accum(self.ctx, ctypes.c_void_p(device_ptr)), "bindAccum")
+        self._check(self.L.rt_bind_accum(self.ctx, ctypes.c_void_p(device_ptr or 0)), "bindAccum")
+
+    def bindPresentSource(self, device_ptr):
+        """present() reads this float4 device buffer instead of the accumulation buffer (0 / None = default)."""
+        self._check(self.L.rt_bind_present_source(self.ctx, ctypes.c_void_p(device_ptr or 0)), "bindPresentSource")
 
     def resetCounters(self):
         self._check(self.L.rt_reset_counters(self.ctx), "resetCounters")
@@ -297,6 +303,21 @@ class WebGPURenderer:
         self._check(self.L.rt_kernel_time_ms(self.ctx, ctypes.byref(pt), ctypes.byref(pv), ctypes.byref(n)),
                     "kernelTimeMs")
         return {"pathtrace_ms": pt.value, "primary_ms": pv.value, "launches": n.value}
+
+
+TIMER_NAMES = ("primary", "pathtrace", "wf_shade", "wf_trace_shadow", "wf_trace_ext", "post")
+
+
+def _kernel_times(self):
+    """{timer: {"ms": sum of durations, "launches": n}} since the last read (rt_kernel_times)."""
+    n = len(TIMER_NAMES)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_uint32 * n)()
+    self._check(self.L.rt_kernel_times(self.ctx, ms, cnt, n), "kernelTimes")
+    return {TIMER_NAMES[k]: {"ms": ms[k], "launches": int(cnt[k])} for k in range(n)}
+
+
+WebGPURenderer.kernelTimes = _kernel_times
 
 
 def upload_scene(renderer, bridge, width, height):
