@@ -9,11 +9,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -99,7 +103,7 @@ struct rt_ctx {
 
   // kernel timing
   bool timing = false;
-  std::vector<EventPair> ev_pool;
+  std::deque<EventPair> ev_pool;   // deque: pointers handed out by next_events stay valid while later timers nest inside
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_tags;  // (pool index, RT_TIMER_* of mi355rt.h)
 
@@ -327,7 +331,19 @@ int rt_device_count(void) {
   return n;
 }
 
+// MI355RT_DEBUG_TERMINATE=1: print a native backtrace when an exception escapes (the HIP runtime throws from inside
+// some calls; without this only "terminate called" is seen).
+static void debug_terminate() {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  fprintf(stderr, "mi355rt: std::terminate, native backtrace:\n");
+  backtrace_symbols_fd(frames, n, 2);
+  abort();
+}
+
 rt_ctx* rt_create(int device_ordinal) {
+  if (const char* dbg = getenv("MI355RT_DEBUG_TERMINATE"))
+    if (dbg[0] == '1') std::set_terminate(debug_terminate);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {

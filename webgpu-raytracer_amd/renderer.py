@@ -22,6 +22,31 @@ class RendererError(RuntimeError):
     pass
 
 
+_hip_runtime = None
+
+
+def _preload_hip_runtime():
+    """ONE HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it
+    as `libamdhip64.so`; libmi355rt.so asks for `libamdhip64.so.7` (RUNPATH /opt/rocm).  The loader matches by the
+    requested name, so whichever came second used to get a second copy of the runtime: `import torch` after the renderer
+    then found "No HIP GPUs", and stream handles or events of one copy meant nothing to the other.  When torch is installed
+    its copy is therefore loaded first, globally — our NEEDED entry matches its SONAME, torch's later request resolves to
+    the same file — and the renderer, torch and RCCL share one runtime whatever the import order.  Without torch (or with
+    MI355RT_HIP_RUNTIME=<path to a libamdhip64.so>) the system runtime of the RUNPATH is used.  No GPU is touched here."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return
+    path = os.environ.get("MI355RT_HIP_RUNTIME")
+    if not path:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL) if path else False
+
+
 def load_library(path=None):
     """dlopen libmi355rt.so and declare every symbol of include/mi355rt.h.
     Loading does not touch the GPU; rt_create does."""
@@ -32,6 +57,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise RendererError(
             "HIP renderer library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    _preload_hip_runtime()
     L = ctypes.CDLL(path)
     vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
     sigs = {
