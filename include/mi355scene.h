@@ -65,6 +65,12 @@ size_t ms_world_node_count(const ms_world* w);
 typedef int (*ms_blas_builder)(void* user, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
                                float* nodes_out, uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
 void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user);
+/* The CPU builder itself, with the hook's signature minus `user`: BVHBuilder::new + build_with_ids of bvh/blas.rs:20-85
+ * on one mesh (4 f32 per vertex, 3 u32 per triangle) -> 8 f32 per node {min.xyz, bits(skip)} {max.xyz, bits(data)} and
+ * the triangle order.  0 on success, -1 on a bad argument.  tests/test_bvh_independent.py pins it with node arrays
+ * worked out by hand from the Rust source. */
+int ms_build_blas(const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
+                  uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
 /* World::update_camera(width, height) lib.rs:347-352. */
 void ms_world_update_camera(ms_world* w, float width, float height);
 

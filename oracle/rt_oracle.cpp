@@ -1221,6 +1221,62 @@ void oracle_get_counters(oracle_ctx* c, uint64_t out[6]) {
 }
 void oracle_reset_counters(oracle_ctx* c) { c->o.counters = Counters(); }
 
+// ---- BVH validity check (tests/test_bvh_independent.py): the restated traversal against brute force ----
+// rays: n x 8 f32 {o.xyz, t_min, d.xyz, t_max}.  out_bvh: n x 3 f32 {t, tri, inst} of intersect_tlas (Raytracer.wgsl:496-528).
+// out_brute: n x 4 f32 {t, tri, inst, ties}: hit_triangle_raw (:443-453) on EVERY triangle of EVERY instance, the
+// triangle range of an instance taken from its draw command (lib.rs:237-262) — no node array involved; the smallest t
+// wins, on equal t the lowest (instance, triangle); ties = number of pairs sharing that smallest t.
+// skip_tri (may be NULL): one byte per triangle, non-zero = brute force leaves it out (the triangles a fallback leaf with
+// more than 7 entries loses to the 3-bit count overflow of blas.rs:111-115, which the reference's traversal never sees).
+void oracle_trace_vs_brute_force(oracle_ctx* c, const float* rays, uint32_t n, float* out_bvh, float* out_brute,
+                                 const uint8_t* skip_tri) {
+  Oracle& o = c->o;
+  const uint32_t saved_w = o.width, saved_h = o.height;
+  const uint32_t sr = o.stripe_rows;
+  o.stripe_rows = 0;       // parallel_spans over a fake n x 1 image: one item per 128 rays
+  o.width = n;
+  o.height = 1;
+  const uint32_t n_inst = (uint32_t)o.instances.size();
+  o.parallel_spans(false, [&](uint32_t, uint32_t x0, uint32_t x1, Counters& cn) {
+    for (uint32_t k = x0; k < x1; k++) {
+      const float* q = rays + (size_t)k * 8;
+      Ray r = make_ray(rt3_make(q[0], q[1], q[2]), rt3_make(q[4], q[5], q[6]));
+      HitResult h = o.intersect_tlas(r, q[3], q[7], cn);
+      out_bvh[k * 3 + 0] = h.t;
+      out_bvh[k * 3 + 1] = h.tri_idx;
+      out_bvh[k * 3 + 2] = (float)h.inst_idx;
+      float best_t = q[7], best_tri = -1.0f, best_inst = -1.0f, ties = 0.0f;
+      for (uint32_t i = 0; i < n_inst && o.draw_commands.size() >= (size_t)4 * n_inst; i++) {
+        const rt_instance& inst = o.instances[i];
+        Ray rl = make_ray(rt_mat_mul_point(inst.inverse, r.origin), rt_mat_mul_dir(inst.inverse, r.direction));
+        const uint32_t first = o.draw_commands[4 * i + 2] / 3u, count = o.draw_commands[4 * i] / 3u;
+        for (uint32_t t = first; t < first + count; t++) {
+          if (skip_tri && skip_tri[t]) continue;
+          const rt_topology& tr = o.topology[t];
+          float tt = Oracle::hit_triangle_raw(o.get_pos(tr.v0), o.get_pos(tr.v1), o.get_pos(tr.v2), rl, q[3], q[7]);
+          if (tt > 0.0f) {
+            if (tt < best_t) {
+              best_t = tt;
+              best_tri = (float)t;
+              best_inst = (float)i;
+              ties = 1.0f;
+            } else if (tt == best_t) {
+              ties += 1.0f;
+            }
+          }
+        }
+      }
+      out_brute[k * 4 + 0] = best_t;
+      out_brute[k * 4 + 1] = best_tri;
+      out_brute[k * 4 + 2] = best_inst;
+      out_brute[k * 4 + 3] = ties;
+    }
+  });
+  o.width = saved_w;
+  o.height = saved_h;
+  o.stripe_rows = sr;
+}
+
 // ---- unit-level entry points for known-answer tests ----
 uint32_t oracle_init_rng(uint32_t pixel_idx, uint32_t frame) { return Oracle::init_rng(pixel_idx, frame); }
 float oracle_rand_pcg(uint32_t* state) { return Oracle::rand_pcg(state); }

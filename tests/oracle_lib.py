@@ -44,6 +44,7 @@ def lib():
             "oracle_read_accum": [vp, vp], "oracle_write_accum": [vp, vp], "oracle_read_gbuffer": [vp, vp, vp, vp],
             "oracle_read_history": [vp, vp], "oracle_read_uniforms": [vp, vp], "oracle_get_counters": [vp, vp],
             "oracle_reset_counters": [vp], "oracle_resize_texture": [vp, u32, u32, vp],
+            "oracle_trace_vs_brute_force": [vp, vp, u32, vp, vp, vp],
         }.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None
@@ -209,3 +210,13 @@ class OracleRenderer:
 
     def resetCounters(self):
         self.L.oracle_reset_counters(self.ctx)
+
+    def traceVsBruteForce(self, rays, skip_tri=None):
+        """rays (n, 8) f32 {o, t_min, d, t_max} -> (bvh (n, 3) {t, tri, inst}, brute (n, 4) {t, tri, inst, ties})"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        skip = None if skip_tri is None else np.ascontiguousarray(skip_tri, dtype=np.uint8)
+        n = rays.shape[0]
+        bvh = np.empty((n, 3), np.float32)
+        brute = np.empty((n, 4), np.float32)
+        self.L.oracle_trace_vs_brute_force(self.ctx, _ptr(rays), n, _ptr(bvh), _ptr(brute), None if skip is None else _ptr(skip))
+        return bvh, brute

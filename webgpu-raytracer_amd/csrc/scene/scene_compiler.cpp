@@ -1578,6 +1578,25 @@ void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user) {
   w->blas_hook = fn;
   w->blas_hook_user = user;
 }
+int ms_build_blas(const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
+                  uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out) {
+  if (!n_nodes_out) return -1;
+  *n_nodes_out = 0;
+  if (n_tris == 0) return 0;
+  if (!verts4 || !indices || !nodes_out || !order_out) return -1;
+  std::vector<uint32_t> idx(indices, indices + (size_t)n_tris * 3);
+  for (uint32_t v : idx)
+    if (v >= n_verts) return -1;
+  BlasBuilder bb(verts4, n_verts, idx);
+  bb.build();
+  if (bb.nodes.size() > nodes_cap) return -1;
+  std::vector<float> packed;
+  pack_nodes(bb.nodes, packed);
+  std::memcpy(nodes_out, packed.data(), packed.size() * 4);
+  for (size_t i = 0; i < bb.order.size(); i++) order_out[i] = (uint32_t)bb.order[i];
+  *n_nodes_out = (uint32_t)bb.nodes.size();
+  return 0;
+}
 size_t ms_world_node_count(const ms_world* w) { return w ? w->gltf.nodes.size() : 0; }
 size_t ms_world_encoded_texture_count(const ms_world* w) { return w ? w->scene.textures.size() : 0; }
 const uint8_t* ms_world_encoded_texture(const ms_world* w, size_t index, size_t* size) {
