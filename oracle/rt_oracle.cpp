@@ -110,6 +110,11 @@ struct Oracle {
   // optional pixel-ownership mask for sharded rendering (stripes of rows)
   uint32_t stripe_rows = 0, stripe_rank = 0, stripe_count = 1;
   Counters counters;
+  // optional per-node visit histogram (oracle_set_node_histogram): one relaxed atomic add per node visit
+  std::atomic<uint32_t>* node_hist = nullptr;
+  void visit(uint32_t node) const {
+    if (node_hist) node_hist[node].fetch_add(1, std::memory_order_relaxed);
+  }
 
   // ------------------------------------------------------------ accessors
   rt3 get_pos(uint32_t i) const { return rt3_make(pos[i * 4], pos[i * 4 + 1], pos[i * 4 + 2]); }
@@ -386,6 +391,7 @@ struct Oracle {
     while (curr < end_node) {
       const rt_node& node = nodes[curr];
       c.nodes_visited++;
+      visit(curr);
       float t_aabb = intersect_aabb(node, r, t_min, closest_t);
       if (t_aabb < T_MAX) {
         uint32_t data = node.data;
@@ -420,6 +426,7 @@ struct Oracle {
     while (curr < end_node) {
       const rt_node& node = nodes[curr];
       c.nodes_visited++;
+      visit(curr);
       if (intersect_aabb(node, r, t_min, res.t) < T_MAX) {
         uint32_t data = node.data;
         if (data != 0u) {
@@ -449,6 +456,7 @@ struct Oracle {
     while (curr < end_node) {
       const rt_node& node = nodes[curr];
       c.nodes_visited++;
+      visit(curr);
       float t_aabb = intersect_aabb(node, r, t_min, t_max);
       if (t_aabb < T_MAX) {
         uint32_t data = node.data;
@@ -477,6 +485,7 @@ struct Oracle {
     while (curr < end_node) {
       const rt_node& node = nodes[curr];
       c.nodes_visited++;
+      visit(curr);
       float t_aabb = intersect_aabb(node, r, t_min, t_max);
       if (t_aabb < T_MAX) {
         uint32_t data = node.data;
@@ -1275,6 +1284,12 @@ void oracle_trace_vs_brute_force(oracle_ctx* c, const float* rays, uint32_t n, f
   o.width = saved_w;
   o.height = saved_h;
   o.stripe_rows = sr;
+}
+
+// per-node visit counts of the following compute() calls (n_nodes u32, zeroed here); NULL switches the histogram off
+void oracle_set_node_histogram(oracle_ctx* c, uint32_t* hist) {
+  c->o.node_hist = reinterpret_cast<std::atomic<uint32_t>*>(hist);
+  if (hist) std::memset(hist, 0, c->o.nodes.size() * 4);
 }
 
 // ---- unit-level entry points for known-answer tests ----

@@ -44,7 +44,7 @@ def lib():
             "oracle_read_accum": [vp, vp], "oracle_write_accum": [vp, vp], "oracle_read_gbuffer": [vp, vp, vp, vp],
             "oracle_read_history": [vp, vp], "oracle_read_uniforms": [vp, vp], "oracle_get_counters": [vp, vp],
             "oracle_reset_counters": [vp], "oracle_resize_texture": [vp, u32, u32, vp],
-            "oracle_trace_vs_brute_force": [vp, vp, u32, vp, vp, vp],
+            "oracle_set_node_histogram": [vp, vp], "oracle_trace_vs_brute_force": [vp, vp, u32, vp, vp, vp],
         }.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None

@@ -6,6 +6,9 @@
 // pure permutations):
 //
 //   nodes      2 x float4 / node   {min.xyz, skip} {max.xyz, data}           (unchanged, 32 B)
+//   tnodes     2 x float4 / node   the same boxes and leaf words with BOTH successors explicit ({.., skip'} {.., inner |
+//              first child'}), ordered most-visited first so that a prefix can live in LDS (k_treelet.hip.h)
+//   inst_root  u32 / inst          index in tnodes of the instance's BLAS root
 //   tri_geom   3 x float4 / tri    {v0, _} {e1 = v1-v0, _} {e2 = v2-v0, _}   (48 B instead of the
 //              80-B topology row + 3 dependent 16-B position gathers, Raytracer.wgsl:476-477)
 //   inst_trav  4 x float4 / inst   rows 0..2 of the inverse matrix (so M*p is 3 dot-like rows),
@@ -23,7 +26,9 @@
 #include "../../include/mi355rt_math.h"
 
 struct DevScene {
-  const float4* nodes;      // 2 per node, TLAS ++ BLAS
+  const float4* nodes;      // 2 per node, TLAS ++ BLAS (bridge layout; the per-lane walks of the primary pass read it)
+  const float4* tnodes;     // 2 per node: the same nodes with explicit successors, treelet first (k_treelet.hip.h)
+  const uint32_t* inst_root;  // 1 per instance: index in tnodes of the instance's BLAS root
   const float4* tri_geom;   // 3 per triangle
   const float4* inst_trav;  // 4 per instance
   const float4* topo;       // 5 per triangle (raw MeshTopology rows)

@@ -208,222 +208,7 @@ __global__ __launch_bounds__(64) void k_pathtrace(DevScene S, DevFrame F, rt_sce
 // Per-path arithmetic and RNG draw order are exactly those of ray_color above (and of the oracle);
 // only the scheduling differs, which cannot change any pixel because paths are independent.
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-struct TravMem {  // pointers may be LDS or global; the template flag keeps the two code paths apart
-  const f4* nodes;
-  const f4* tri_geom;
-  const f4* inst_trav;
-};
-
-__device__ __forceinline__ bool hit_box4(f4 lo, f4 hi, const LocalRay& r, float t_min, float t_max) {
-  float t1x = lo.x * r.inv_d.x - r.o_inv_d.x, t2x = hi.x * r.inv_d.x - r.o_inv_d.x;
-  float t1y = lo.y * r.inv_d.y - r.o_inv_d.y, t2y = hi.y * r.inv_d.y - r.o_inv_d.y;
-  float t1z = lo.z * r.inv_d.z - r.o_inv_d.z, t2z = hi.z * r.inv_d.z - r.o_inv_d.z;
-  float nx = rt_min(t1x, t2x), ny = rt_min(t1y, t2y), nz = rt_min(t1z, t2z);
-  float fx = rt_max(t1x, t2x), fy = rt_max(t1y, t2y), fz = rt_max(t1z, t2z);
-  float tm_near = rt_max(t_min, rt_max(nx, rt_max(ny, nz)));
-  float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
-  return tm_near <= tm_far;
-}
-__device__ __forceinline__ LocalRay to_instance(const TravMem& M, uint32_t inst, rt3 o, rt3 d, uint32_t& blas_off) {
-  f4 r0 = M.inst_trav[4 * inst + 0], r1 = M.inst_trav[4 * inst + 1], r2 = M.inst_trav[4 * inst + 2];
-  blas_off = rt_f2u(M.inst_trav[4 * inst + 3].x);
-  rt3 lo = rt3_make(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w * 1.0f, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w * 1.0f,
-                    r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w * 1.0f);
-  rt3 ld = rt3_make(r0.x * d.x + r0.y * d.y + r0.z * d.z + r0.w * 0.0f, r1.x * d.x + r1.y * d.y + r1.z * d.z + r1.w * 0.0f,
-                    r2.x * d.x + r2.y * d.y + r2.z * d.z + r2.w * 0.0f);
-  return make_ray(lo, ld);
-}
-
-// Branch-free Möller–Trumbore: same operations and the same accept/reject truth table as
-// hit_triangle_raw (Raytracer.wgsl:443-453), evaluated without early exits so that a wave testing
-// 64 different triangles stays converged.
-__device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max, float& t_out) {
-  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
-  rt3 h = rt_cross(r.d, e2);
-  float a = rt_dot(e1, h);
-  float f = 1.0f / a;
-  rt3 s = r.o - v0;
-  float u = f * rt_dot(s, h);
-  rt3 q = rt_cross(s, e1);
-  float v = f * rt_dot(r.d, q);
-  float t = f * rt_dot(e2, q);
-  t_out = t;
-  bool reject = (rt_abs(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
-  return !reject & (t > t_min) & (t < t_max);
-}
-
-// ---------------------------------------------------------------------------------------------
-// traverse(): one walk over TLAS and BLAS nodes for the 64 rays of a wave.
-//
-// Divergence control.  A lane is SEARCHING (walking nodes: slab tests, instance entry/exit) or
-// WAITING (it reached a BLAS leaf whose box it hits and has queued that leaf's triangles).  Every
-// trip of the loop lets all searching lanes take ONE node step.  When enough triangle tests are queued
-// (RT_FLUSH_ITEMS) or nobody is searching any more, the wave flushes the queue:
-//   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
-//     3-bit leaf counts, each owner also posts its instance-space ray;
-//   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
-//     with 6 triangles no longer holds 63 other lanes hostage;
-//   * each owner then folds its own results in leaf order with the reference's strict `t < closest`
-//     rule and goes back to searching.
-// Equivalence with the reference's sequential leaf loop (Raytracer.wgsl:474-482): a test is accepted
-// there iff geometry passes, t > t_min and t < the running closest; the running closest never exceeds
-// the closest at leaf entry, so testing every triangle against the leaf-entry bound in parallel and
-// re-applying `t < running closest` in order during the fold makes exactly the same decisions.
-// Per lane the sequence of visited nodes, tested triangles and tie-breaks is the reference's.
-// ANY = shadow ray (first accepted hit ends the ray), else closest hit.
-struct WaveWork {
-  f4* rays;         // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
-  uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
-};
-#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
-#ifndef RT_WF_WAVES
-#define RT_WF_WAVES 6
-#endif
-#ifndef RT_FLUSH_ITEMS
-#define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
-                            // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
-#endif
-
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void traverse(const TravMem& M, const WaveWork& W, uint32_t blas_base, bool active, rt3 o,
-                                         rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
-                                         int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
-  const uint32_t lane = threadIdx.x & 63u;
-  float closest = t_max;
-  int32_t best_tri = -1, best_inst = -1;
-  bool any = false;
-  bool searching = active && blas_base != 0u;
-  bool waiting = false;
-  uint32_t leaf = 0u;
-  LocalRay r = make_ray(o, d);
-  const uint32_t tlas_end = rt_f2u(M.nodes[0].w);
-  uint32_t curr = 0u, end = tlas_end, base = 0u, tlas_next = 0u;
-  uint32_t cur_inst = 0u;
-  bool in_blas = false;
-  for (;;) {
-#ifdef RT_WAVE_STATS
-    {
-      const bool any_search = __ballot(searching) != 0ull;
-      if (COUNT && lane == 0u && any_search) n_nodes++;  // wave-level node steps
-    }
-#endif
-    // ---- range exhausted (rare): leave the instance, or finish
-    if (searching && curr >= end) {
-      if (in_blas && tlas_next < tlas_end) {
-        in_blas = false;  // back to the world-space ray and the TLAS cursor
-        r = make_ray(o, d);
-        curr = tlas_next;
-        end = tlas_end;
-        base = 0u;
-      } else {
-        searching = false;
-      }
-    }
-    // ---- one node step for every searching lane (curr < end holds); select-based, two branches only
-    if (searching) {
-      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
-#ifndef RT_WAVE_STATS
-      if (COUNT) n_nodes++;
-#endif
-      const bool hit = hit_box4(lo, hi, r, t_min, closest);
-      const uint32_t data = rt_f2u(hi.w);
-      const bool leafhit = hit && data != 0u;
-      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
-      const bool got_leaf = leafhit && in_blas;
-      if (leafhit && !in_blas) {  // TLAS leaf: enter the instance
-        cur_inst = data >> 3;
-        uint32_t off;
-        r = to_instance(M, cur_inst, o, d, off);
-        tlas_next = next;
-        base = blas_base + off;
-        end = base + rt_f2u(M.nodes[2 * base].w);
-        next = base;
-        in_blas = true;
-      }
-      leaf = got_leaf ? data : leaf;
-      waiting = got_leaf;
-      searching = !got_leaf;
-      curr = next;
-    }
-    // ---- flush the triangle queue?
-    const unsigned long long smask = __ballot(searching);
-    const unsigned long long wmask = __ballot(waiting);
-    if ((smask | wmask) == 0ull) break;
-    const uint32_t cnt = waiting ? (leaf & 7u) : 0u;
-    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
-    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
-                           4u * (uint32_t)__builtin_popcountll(b2);
-    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
-      const uint32_t excl =
-          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
-          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
-      const uint32_t first = leaf >> 3;
-      if (waiting) {
-        f4 ra, rb;
-        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = t_min;
-        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
-        W.rays[2 * lane] = ra;
-        W.rays[2 * lane + 1] = rb;
-        const uint32_t tag = lane << 26;
-#pragma unroll
-        for (uint32_t i = 0; i < 7u; i++)
-          if (i < cnt) W.items[excl + i] = tag | (first + i);
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t c = 0; c < total; c += 64u) {
-#ifdef RT_WAVE_STATS
-        if (COUNT && lane == 0u) n_tris++;  // wave-level 64-item chunks
-#endif
-        const uint32_t j = c + lane;
-        if (j < total) {
-          const uint32_t it = W.items[j];
-          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
-          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
-          LocalRay q;
-          q.o = rt3_make(ra.x, ra.y, ra.z);
-          q.d = rt3_make(rb.x, rb.y, rb.z);
-          float t;
-          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
-          W.items[j] = rt_f2u(ok ? t : -1.0f);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (waiting) {
-        // fold this lane's results in leaf order (strict t < closest: the first of equal hits wins)
-        bool stop = false;
-#pragma unroll
-        for (uint32_t i = 0; i < 7u; i++) {
-          if (i < cnt && !stop) {
-#ifndef RT_WAVE_STATS
-            if (COUNT) n_tris++;
-#endif
-            const float t = rt_u2f(W.items[excl + i]);
-            if (t > 0.0f && t < closest) {
-              if (ANY) {
-                any = true;
-                stop = true;
-              } else {
-                closest = t;
-                best_tri = (int32_t)(first + i);
-                best_inst = (int32_t)cur_inst;
-              }
-            }
-          }
-        }
-        waiting = false;
-        searching = !(ANY && any);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  out_t = closest;
-  out_tri = best_tri;
-  out_inst = best_inst;
-  out_any = any;
-}
+// (the wave-level walk itself — TravMem, trav_step, trav_flush, traverse() — is in k_traverse.hip.h)
 
 struct PathState {
   uint32_t pixel, rng, depth, sample;
@@ -578,8 +363,8 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
 // number of 16-byte LDS slots the whole scene needs (traversal records + shading arrays)
 __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
                                                   uint32_t n_lights) {
-  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)2 * n_verts +
-         ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + ((size_t)n_inst + 3) / 4 + (size_t)5 * n_tris +
+         (size_t)2 * n_verts + ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
 }
 
 // Diagnostic build only (-DRT_CLOCK_STAMP, tools/clock_check.py): every workgroup of the persistent kernel stamps
@@ -590,12 +375,57 @@ __device__ unsigned long long g_clock_stamps[2 * RT_CLOCK_STAMP_SLOTS];
 
 // Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
 // is latency bound and gains ~11 % from 6 waves/SIMD even with the spills that costs (measured on MI355X).
+// What a workgroup stages in LDS behind its wave queues (decided on the host from the scene's size, rt_api.hip plan_lds):
+// the first k_nodes records of tnodes, and — when they fit as a whole — the instance rows + BLAS roots and the triangle
+// records.  LDS = true (the whole scene fits, shading arrays included) ignores it.
+struct LdsPlan {
+  uint32_t k_nodes, stage_inst, stage_tri, pad;
+};
+
+// stage `slots` 16-byte records from global memory into LDS at `dst` (all threads of the workgroup; no barrier)
+__device__ __forceinline__ void lds_stage(f4* dst, const void* src, size_t slots) {
+  const f4* g = reinterpret_cast<const f4*>(src);
+  for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) dst[i] = g[i];
+}
+
+// Fill TravMem for the mixed mode and stage what the plan names; returns the number of 16-byte slots used.
+__device__ __forceinline__ uint32_t trav_stage_mixed(TravMem& M, f4* lds, uint32_t slot0, const DevScene& Sg, const LdsPlan& P,
+                                                     uint32_t n_tris_total, uint32_t n_inst_total) {
+  uint32_t slot = slot0;
+  M.gnodes = reinterpret_cast<const f4*>(Sg.tnodes);
+  M.gtri = reinterpret_cast<const f4*>(Sg.tri_geom);
+  M.ginst = reinterpret_cast<const f4*>(Sg.inst_trav);
+  M.groot = Sg.inst_root;
+  M.k_lds = P.k_nodes;
+  M.l_nodes = slot;
+  lds_stage(lds + slot, Sg.tnodes, (size_t)2 * P.k_nodes);
+  slot += 2u * P.k_nodes;
+  M.l_inst = M.l_root = M.l_tri = RT_LDS_NONE;
+  if (P.stage_inst) {
+    M.l_inst = slot;
+    lds_stage(lds + slot, Sg.inst_trav, (size_t)4 * n_inst_total);
+    slot += 4u * n_inst_total;
+    M.l_root = slot;
+    lds_stage(lds + slot, Sg.inst_root, ((size_t)n_inst_total + 3) / 4);   // the buffer has 16 bytes of slack
+    slot += (n_inst_total + 3u) / 4u;
+  }
+  if (P.stage_tri) {
+    M.l_tri = slot;
+    lds_stage(lds + slot, Sg.tri_geom, (size_t)3 * n_tris_total);
+    slot += 3u * n_tris_total;
+  }
+  return slot - slot0;
+}
+
+// Occupancy: the LDS-resident form is latency bound at 4 waves/SIMD (registers), the global-memory form gains ~11 %
+// from 6 waves/SIMD even with the spills that costs (measured on MI355X).
 template <bool DETAIL, bool LDS>
 __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
                                                               uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
                                                               uint32_t n_tris_total, uint32_t n_inst_total,
                                                               uint32_t n_verts_total,
-                                                              const DevFrameSlot* __restrict__ slots, uint32_t n_slots) {
+                                                              const DevFrameSlot* __restrict__ slots, uint32_t n_slots,
+                                                              LdsPlan plan) {
   // Batched dispatch (rt_compute_batch): the launch covers n_slots consecutive compute() frames. The work item is
   // one (frame, pixel): tickets enumerate (frame, tile) pairs, so a launch has n_slots times as many tickets and the
   // persistent waves stay fed and balanced even when a rank owns 1/8 of the image. With n_slots > 1 every item
@@ -609,23 +439,30 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     WW.rays = reinterpret_cast<f4*>(wbase);
     WW.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
   }
-  f4* const s_records = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
+  const uint32_t rec0 = (4 * RT_WORK_BYTES_PER_WAVE) / 16;   // first slot behind the wave queues
   TravMem M;
   DevScene S = Sg;
   if (LDS) {
     // Small scene: the whole scene (traversal records AND the arrays shading reads) lives in LDS,
     // staged once per workgroup; only textures, the G-buffer and the accumulation buffer stay in HBM.
-    f4* dst = s_records;
-    auto stage = [&](const void* src, size_t slots) {
-      const f4* g = reinterpret_cast<const f4*>(src);
-      f4* base = dst;
-      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
-      dst += slots;
+    uint32_t slot = rec0;
+    auto stage = [&](const void* src, size_t n) {
+      f4* base = s_scene + slot;
+      lds_stage(base, src, n);
+      slot += (uint32_t)n;
       return base;
     };
-    f4* ln = stage(Sg.nodes, (size_t)2 * n_nodes_total);
+    M.gnodes = M.gtri = M.ginst = nullptr;
+    M.groot = nullptr;
+    M.k_lds = n_nodes_total;
+    M.l_nodes = slot;
+    f4* ln = stage(Sg.tnodes, (size_t)2 * n_nodes_total);
+    M.l_tri = slot;
     f4* lt = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    M.l_inst = slot;
     f4* li = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
+    M.l_root = slot;
+    stage(Sg.inst_root, ((size_t)n_inst_total + 3) / 4);
     S.topo = reinterpret_cast<const float4*>(stage(Sg.topo, (size_t)5 * n_tris_total));
     S.pos = reinterpret_cast<const float4*>(stage(Sg.pos, n_verts_total));
     S.nrm = reinterpret_cast<const float4*>(stage(Sg.nrm, n_verts_total));
@@ -635,17 +472,14 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     S.lights = reinterpret_cast<const uint2*>(stage(Sg.lights, ((size_t)Sg.n_lights + 1) / 2));
     S.light_rec = reinterpret_cast<const float4*>(stage(Sg.light_rec, (size_t)4 * Sg.n_lights));
     __syncthreads();
-    M.nodes = ln;
-    M.tri_geom = lt;
-    M.inst_trav = li;
-    S.nodes = reinterpret_cast<const float4*>(ln);
+    S.tnodes = reinterpret_cast<const float4*>(ln);
     S.tri_geom = reinterpret_cast<const float4*>(lt);
     S.inst_trav = reinterpret_cast<const float4*>(li);
   } else {
-    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
-    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
-    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
+    trav_stage_mixed(M, s_scene, rec0, Sg, plan, n_tris_total, n_inst_total);
+    __syncthreads();
   }
+  constexpr int MODE = LDS ? RT_TRAV_LDS : RT_TRAV_MIXED;
 
 #ifdef RT_CLOCK_STAMP
   const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
@@ -760,13 +594,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     bool nee_valid = false;
     rt3 sh_o = rt3_splat(0.0f), sh_d = rt3_splat(0.0f), nee = rt3_splat(0.0f);
     float sh_tmax = 0.0f;
-#ifdef RT_WAVE_STATS
-    if (DETAIL && lane == 0u) cnt_shaded++;  // wave-level outer trips
-#endif
     if (running) {
-#ifndef RT_WAVE_STATS
       if (DETAIL) cnt_shaded++;
-#endif
       BounceOut bo;
       shade_bounce(S, U.light_count, F.max_depth, p, bo);
       want_shadow = bo.want_shadow;
@@ -791,8 +620,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t a_, b_;
       bool occluded;
-      traverse<true, DETAIL>(M, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_, occluded,
-                             cnt_nodes, cnt_tris);
+      traverse<true, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_,
+                                   occluded, cnt_nodes, cnt_tris);
       if (want_shadow) {
         cnt_shadow++;
         if (!occluded && nee_valid) p.radiance = p.radiance + nee;  // nothing is added when bsdf_pdf <= 0
@@ -804,8 +633,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t tri_, inst_;
       bool any_;
-      traverse<false, DETAIL>(M, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_, inst_, any_,
-                              cnt_nodes, cnt_tris);
+      traverse<false, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_,
+                                    inst_, any_, cnt_nodes, cnt_tris);
       if (want_extend) {
         cnt_ext++;
         if (inst_ < 0) {

@@ -1,0 +1,288 @@
+// k_traverse.hip.h — the wave-level TLAS / BLAS walk shared by the persistent kernel (traverse()) and the wavefront
+// trace kernel (k_wf_trace): ONE copy of the node step and of the LDS triangle queue (Raytracer.wgsl:455-600).
+// Part of the kernel set of csrc/kernels.hip.h (included from there, in order; not a stand-alone header).
+#ifndef MI355RT_K_TRAVERSE_HIP_H
+#define MI355RT_K_TRAVERSE_HIP_H
+
+namespace rtk {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Where the traversal records live.  `tnodes` (k_treelet.hip.h) has its first k_lds nodes staged in LDS at slot l_nodes
+// of the workgroup's dynamic LDS array; the triangle records, the instance rows and the instance BLAS roots are staged
+// as a whole when they fit (l_* != RT_LDS_NONE), else read through L1 / L2.  Slots are 16-byte units.
+#define RT_LDS_NONE 0xffffffffu
+struct TravMem {
+  const f4* gnodes;           // tnodes, 2 per node
+  const f4* gtri;             // tri_geom, 3 per triangle
+  const f4* ginst;            // inst_trav, 4 per instance
+  const uint32_t* groot;      // inst_root, 1 per instance: index in tnodes of the instance's BLAS root
+  uint32_t k_lds;             // nodes [0, k_lds) are read from LDS
+  uint32_t l_nodes, l_tri, l_inst, l_root;
+};
+
+// MODE_LDS: every record is in LDS (the whole scene fits: k_lds >= n_nodes and all l_* set) — the compiler sees plain
+// ds_read.  MODE_MIXED: per-access choice (a lane-level compare for nodes, wave-uniform flags for the rest).
+enum { RT_TRAV_LDS = 1, RT_TRAV_MIXED = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void trav_fetch_node(const TravMem& M, const f4* lds, uint32_t idx, f4& lo, f4& hi) {
+  if (MODE == RT_TRAV_LDS || idx < M.k_lds) {
+    lo = lds[M.l_nodes + 2u * idx];
+    hi = lds[M.l_nodes + 2u * idx + 1u];
+  } else {
+    lo = M.gnodes[2 * (size_t)idx];
+    hi = M.gnodes[2 * (size_t)idx + 1];
+  }
+}
+
+__device__ __forceinline__ bool hit_box4(f4 lo, f4 hi, const LocalRay& r, float t_min, float t_max) {
+  float t1x = lo.x * r.inv_d.x - r.o_inv_d.x, t2x = hi.x * r.inv_d.x - r.o_inv_d.x;
+  float t1y = lo.y * r.inv_d.y - r.o_inv_d.y, t2y = hi.y * r.inv_d.y - r.o_inv_d.y;
+  float t1z = lo.z * r.inv_d.z - r.o_inv_d.z, t2z = hi.z * r.inv_d.z - r.o_inv_d.z;
+  float nx = rt_min(t1x, t2x), ny = rt_min(t1y, t2y), nz = rt_min(t1z, t2z);
+  float fx = rt_max(t1x, t2x), fy = rt_max(t1y, t2y), fz = rt_max(t1z, t2z);
+  float tm_near = rt_max(t_min, rt_max(nx, rt_max(ny, nz)));
+  float tm_far = rt_min(t_max, rt_min(fx, rt_min(fy, fz)));
+  return tm_near <= tm_far;
+}
+
+// instance entry: object-space ray + the BLAS root (Raytracer.wgsl:507-512)
+template <int MODE>
+__device__ __forceinline__ LocalRay to_instance(const TravMem& M, const f4* lds, uint32_t inst, rt3 o, rt3 d,
+                                                uint32_t& blas_root) {
+  f4 r0, r1, r2;
+  if (MODE == RT_TRAV_LDS || M.l_inst != RT_LDS_NONE) {
+    r0 = lds[M.l_inst + 4u * inst + 0u];
+    r1 = lds[M.l_inst + 4u * inst + 1u];
+    r2 = lds[M.l_inst + 4u * inst + 2u];
+    blas_root = reinterpret_cast<const uint32_t*>(lds + M.l_root)[inst];
+  } else {
+    r0 = M.ginst[4 * (size_t)inst + 0];
+    r1 = M.ginst[4 * (size_t)inst + 1];
+    r2 = M.ginst[4 * (size_t)inst + 2];
+    blas_root = M.groot[inst];
+  }
+  rt3 lo = rt3_make(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w * 1.0f, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w * 1.0f,
+                    r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w * 1.0f);
+  rt3 ld = rt3_make(r0.x * d.x + r0.y * d.y + r0.z * d.z + r0.w * 0.0f, r1.x * d.x + r1.y * d.y + r1.z * d.z + r1.w * 0.0f,
+                    r2.x * d.x + r2.y * d.y + r2.z * d.z + r2.w * 0.0f);
+  return make_ray(lo, ld);
+}
+
+// Branch-free Möller–Trumbore: same operations and the same accept/reject truth table as
+// hit_triangle_raw (Raytracer.wgsl:443-453), evaluated without early exits so that a wave testing
+// 64 different triangles stays converged.
+__device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& r, float t_min, float t_max, float& t_out) {
+  rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
+  rt3 h = rt_cross(r.d, e2);
+  float a = rt_dot(e1, h);
+  float f = 1.0f / a;
+  rt3 s = r.o - v0;
+  float u = f * rt_dot(s, h);
+  rt3 q = rt_cross(s, e1);
+  float v = f * rt_dot(r.d, q);
+  float t = f * rt_dot(e2, q);
+  t_out = t;
+  bool reject = (rt_abs(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+  return !reject & (t > t_min) & (t < t_max);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One walk over TLAS and BLAS nodes for the 64 rays of a wave.
+//
+// Divergence control.  A lane is SEARCHING (walking nodes: slab tests, instance entry/exit) or
+// WAITING (it reached a BLAS leaf whose box it hits and has queued that leaf's triangles).  Every
+// trip lets all searching lanes take ONE node step (trav_step).  When enough triangle tests are queued
+// (RT_FLUSH_ITEMS) or nobody is searching any more, the wave flushes the queue (trav_flush):
+//   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
+//     3-bit leaf counts, each owner also posts its instance-space ray;
+//   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
+//     with 6 triangles no longer holds 63 other lanes hostage;
+//   * each owner then folds its own results in leaf order with the reference's strict `t < closest`
+//     rule and goes back to searching.
+// Equivalence with the reference's sequential leaf loop (Raytracer.wgsl:474-482): a test is accepted
+// there iff geometry passes, t > t_min and t < the running closest; the running closest never exceeds
+// the closest at leaf entry, so testing every triangle against the leaf-entry bound in parallel and
+// re-applying `t < running closest` in order during the fold makes exactly the same decisions.
+// Per lane the sequence of visited nodes, tested triangles and tie-breaks is the reference's: the walk follows the
+// explicit successors of tnodes, which name the same nodes as `curr + 1` / `node_start + skip` do in the bridge array.
+// ANY = shadow ray (first accepted hit ends the ray), else closest hit.
+struct WaveWork {
+  f4* rays;         // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
+  uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
+};
+#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#ifndef RT_FLUSH_ITEMS
+#define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
+                            // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
+#endif
+
+struct Trav {  // one ray's traversal state
+  LocalRay r;                // the ray in the space it is currently walking (world or instance)
+  rt3 o, d;                  // world-space ray
+  float t_min, closest;
+  int32_t best_tri, best_inst;
+  uint32_t curr, tlas_next, cur_inst, leaf;
+  bool searching, waiting, in_blas, any;
+};
+
+__device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_min, float t_max) {
+  s.o = o;
+  s.d = d;
+  s.r = make_ray(o, d);
+  s.t_min = t_min;
+  s.closest = t_max;
+  s.best_tri = -1;
+  s.best_inst = -1;
+  s.curr = 0u;               // the TLAS root is node 0 of tnodes
+  s.tlas_next = RT_NODE_END;
+  s.cur_inst = 0u;
+  s.leaf = 0u;
+  s.searching = active && blas_base != 0u;
+  s.waiting = false;
+  s.in_blas = false;
+  s.any = false;
+}
+
+// one node step for every searching lane; select-based, two branches only
+template <bool COUNT, int MODE>
+__device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
+  // ---- the walk ran off its array (rare): leave the instance, or finish
+  if (s.searching && s.curr == RT_NODE_END) {
+    if (s.in_blas && s.tlas_next != RT_NODE_END) {
+      s.in_blas = false;  // back to the world-space ray and the TLAS cursor
+      s.r = make_ray(s.o, s.d);
+      s.curr = s.tlas_next;
+    } else {
+      s.searching = false;
+    }
+  }
+  if (s.searching) {
+    f4 lo, hi;
+    trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
+    if (COUNT) n_nodes++;
+    const bool hit = hit_box4(lo, hi, s.r, s.t_min, s.closest);
+    const uint32_t data = rt_f2u(hi.w);
+    const bool inner = (data & RT_NODE_INNER) != 0u;
+    const bool leafhit = hit && !inner;
+    uint32_t next = (hit && inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
+    const bool got_leaf = leafhit && s.in_blas;
+    if (leafhit && !s.in_blas) {  // TLAS leaf: enter the instance
+      s.cur_inst = data >> 3;
+      uint32_t root;
+      s.r = to_instance<MODE>(M, lds, s.cur_inst, s.o, s.d, root);
+      s.tlas_next = next;
+      next = root;
+      s.in_blas = true;
+    }
+    s.leaf = got_leaf ? data : s.leaf;
+    s.waiting = got_leaf;
+    s.searching = !got_leaf;
+    s.curr = next;
+  }
+}
+
+// Flush the wave's triangle queue when it is due.  Returns false when no lane is searching or waiting any more
+// (the walk of every ray of the wave is over) — `idle_ok` callers (k_wf_trace) ignore that and refill instead.
+template <bool ANY, bool COUNT, int MODE>
+__device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s, uint32_t& n_tris) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long smask = __ballot(s.searching);
+  const unsigned long long wmask = __ballot(s.waiting);
+  if ((smask | wmask) == 0ull) return false;
+  if (wmask == 0ull) return true;
+  const uint32_t cnt = s.waiting ? (s.leaf & 7u) : 0u;
+  const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+  const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                         4u * (uint32_t)__builtin_popcountll(b2);
+  if (total < RT_FLUSH_ITEMS && smask != 0ull) return true;
+  const uint32_t excl =
+      __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+      2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+      4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+  const uint32_t first = s.leaf >> 3;
+  if (s.waiting) {
+    f4 ra, rb;
+    ra.x = s.r.o.x; ra.y = s.r.o.y; ra.z = s.r.o.z; ra.w = s.t_min;
+    rb.x = s.r.d.x; rb.y = s.r.d.y; rb.z = s.r.d.z; rb.w = s.closest;
+    W.rays[2 * lane] = ra;
+    W.rays[2 * lane + 1] = rb;
+    const uint32_t tag = lane << 26;
+#pragma unroll
+    for (uint32_t i = 0; i < 7u; i++)
+      if (i < cnt) W.items[excl + i] = tag | (first + i);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const bool tri_lds = MODE == RT_TRAV_LDS || M.l_tri != RT_LDS_NONE;   // wave-uniform
+  for (uint32_t c = 0; c < total; c += 64u) {
+    const uint32_t j = c + lane;
+    if (j < total) {
+      const uint32_t it = W.items[j];
+      const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
+      f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
+      LocalRay q;
+      q.o = rt3_make(ra.x, ra.y, ra.z);
+      q.d = rt3_make(rb.x, rb.y, rb.z);
+      f4 g0, g1, g2;
+      if (tri_lds) {
+        g0 = lds[M.l_tri + 3u * tri];
+        g1 = lds[M.l_tri + 3u * tri + 1u];
+        g2 = lds[M.l_tri + 3u * tri + 2u];
+      } else {
+        g0 = M.gtri[3 * (size_t)tri];
+        g1 = M.gtri[3 * (size_t)tri + 1];
+        g2 = M.gtri[3 * (size_t)tri + 2];
+      }
+      float t;
+      bool ok = hit_tri_nb(g0, g1, g2, q, ra.w, rb.w, t);
+      W.items[j] = rt_f2u(ok ? t : -1.0f);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (s.waiting) {
+    // fold this lane's results in leaf order (strict t < closest: the first of equal hits wins)
+    bool stop = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 7u; i++) {
+      if (i < cnt && !stop) {
+        if (COUNT) n_tris++;
+        const float t = rt_u2f(W.items[excl + i]);
+        if (t > 0.0f && t < s.closest) {
+          if (ANY) {
+            s.any = true;
+            stop = true;
+          } else {
+            s.closest = t;
+            s.best_tri = (int32_t)(first + i);
+            s.best_inst = (int32_t)s.cur_inst;
+          }
+        }
+      }
+    }
+    s.waiting = false;
+    s.searching = !stop;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+// traverse(): the whole walk of one wave's rays (persistent kernel, one traversal per bounce and ray kind)
+template <bool ANY, bool COUNT, int MODE>
+__device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const WaveWork& W, uint32_t blas_base, bool active,
+                                         rt3 o, rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
+                                         int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
+  Trav s;
+  trav_begin(s, active, blas_base, o, d, t_min, t_max);
+  for (;;) {
+    trav_step<COUNT, MODE>(M, lds, s, n_nodes);
+    if (!trav_flush<ANY, COUNT, MODE>(M, lds, W, s, n_tris)) break;
+  }
+  out_t = s.closest;
+  out_tri = s.best_tri;
+  out_inst = s.best_inst;
+  out_any = s.any;
+}
+
+}  // namespace rtk
+#endif

@@ -184,10 +184,16 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 
 // Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
 // else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
-template <bool ANY, bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws,
-                                                            WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
-                                                            uint32_t n_tris_total, uint32_t n_inst_total) {
+// BLOCK threads per workgroup (256 / 512 / 1024): a bigger workgroup shares one staged treelet among more waves, so
+// the LDS copy of the top of the tree can be larger (LdsPlan, rt_api.hip plan_lds) at the price of fewer waves per SIMD
+// than the 256-thread form allows.  LDS = true: every traversal record fits (RT_TRAV_LDS).
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 6
+#endif
+template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
+void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
+                uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
   extern __shared__ f4 s_scene[];
   WaveWork W;
   {
@@ -195,25 +201,19 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
     W.rays = reinterpret_cast<f4*>(wbase);
     W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
   }
+  const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
   TravMem M;
   if (LDS) {
-    f4* dst = s_scene + (4 * RT_WORK_BYTES_PER_WAVE) / 16;
-    auto stage = [&](const void* src, size_t slots) {
-      const f4* g = reinterpret_cast<const f4*>(src);
-      f4* base = dst;
-      for (uint32_t i = threadIdx.x; i < slots; i += 256) base[i] = g[i];
-      dst += slots;
-      return base;
-    };
-    M.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
-    M.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
-    M.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
-    __syncthreads();
+    LdsPlan all;
+    all.k_nodes = n_nodes_total;
+    all.stage_inst = all.stage_tri = 1u;
+    all.pad = 0u;
+    trav_stage_mixed(M, s_scene, rec0, Sg, all, n_tris_total, n_inst_total);
   } else {
-    M.nodes = reinterpret_cast<const f4*>(Sg.nodes);
-    M.tri_geom = reinterpret_cast<const f4*>(Sg.tri_geom);
-    M.inst_trav = reinterpret_cast<const f4*>(Sg.inst_trav);
+    trav_stage_mixed(M, s_scene, rec0, Sg, plan, n_tris_total, n_inst_total);
   }
+  __syncthreads();
+  constexpr int MODE = LDS ? RT_TRAV_LDS : RT_TRAV_MIXED;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t blas_base = U.blas_base_idx;
   uint32_t* cnt = Q.counters + 8u * depth;
@@ -221,15 +221,12 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
   uint32_t* head = ANY ? &cnt[3] : &cnt[4];
   uint32_t* next_active = Q.active[(depth + 1u) & 1u];
   uint32_t* next_count = Q.counters + 8u * (depth + 1u);
-  const uint32_t tlas_end = blas_base ? rt_f2u(M.nodes[0].w) : 0u;
 
   // per-lane ray + traversal state
-  bool have_ray = false, searching = false, waiting = false, in_blas = false, any = false;
-  uint32_t id = 0u, leaf = 0u, curr = 0u, end = 0u, base = 0u, tlas_next = 0u, cur_inst = 0u;
-  rt3 o = rt3_splat(0.0f), d = rt3_splat(0.0f);
-  float t_max = 0.0f, closest = 0.0f;
-  int32_t best_tri = -1, best_inst = -1;
-  LocalRay r = make_ray(rt3_splat(1.0f), rt3_splat(1.0f));
+  bool have_ray = false;
+  uint32_t id = 0u;
+  Trav s;
+  trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), RT_T_MIN, 0.0f);
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
   WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
@@ -237,10 +234,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
 
   for (;;) {
     // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
-    const bool done = have_ray && !searching && !waiting;
+    const bool done = have_ray && !s.searching && !s.waiting;
     const bool idle = !have_ray || done;
     const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
-    const unsigned long long busy_m = __ballot(searching || waiting);
+    const unsigned long long busy_m = __ballot(s.searching || s.waiting);
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
          (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
@@ -249,7 +246,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
         if (ANY) {
           float4 dd = Ws.p[id].d;
           const uint32_t fl = rt_f2u(dd.w);
-          if (!any && (fl & WF_FLAG_NEE_VALID) != 0u) {
+          if (!s.any && (fl & WF_FLAG_NEE_VALID) != 0u) {
             const float4 e = Ws.p[id].e;
             dd.x = dd.x + e.x;  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
             dd.y = dd.y + e.y;
@@ -260,17 +257,17 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
           else
             Ws.p[id].d = dd;
         } else {
-          if (best_inst < 0) {  // miss: the path ends with what it has
+          if (s.best_inst < 0) {  // miss: the path ends with what it has
             const float4 dd = Ws.p[id].d;
             F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
           } else {
             float4 a = Ws.p[id].a;
-            a.w = closest;
+            a.w = s.closest;
             Ws.p[id].a = a;
             float4 e = Ws.p[id].e;
-            e.w = rt_u2f((uint32_t)best_tri);
+            e.w = rt_u2f((uint32_t)s.best_tri);
             Ws.p[id].e = e;
-            Ws.p[id].inst = (uint32_t)best_inst;
+            Ws.p[id].inst = (uint32_t)s.best_inst;
             float4 dd = Ws.p[id].d;
             const uint32_t fl = rt_f2u(dd.w);
             dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
@@ -308,6 +305,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
             const uint32_t rid = ANY ? Q.shadow_ids[qi] : Q.ext_ids[qi];
             if (rid != RT_WF_INVALID) {
               id = rid;
+              rt3 o, d;
+              float t_max;
               if (ANY) {
                 const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
                 o = xyz(r0);
@@ -320,17 +319,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
               }
               n_traced++;
               have_ray = true;
-              closest = t_max;
-              best_tri = -1;
-              best_inst = -1;
-              any = false;
-              r = make_ray(o, d);
-              curr = 0u;
-              end = tlas_end;
-              base = 0u;
-              in_blas = false;
-              searching = blas_base != 0u;
-              waiting = false;
+              trav_begin(s, true, blas_base, o, d, RT_T_MIN, t_max);
             }
           }
         }
@@ -338,110 +327,12 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_WF_WAVES) void k_wf_trace(DevScen
     }
     if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
 
-    // ---- range exhausted: leave the instance, or finish the ray
-    if (searching && curr >= end) {
-      if (in_blas && tlas_next < tlas_end) {
-        in_blas = false;
-        r = make_ray(o, d);
-        curr = tlas_next;
-        end = tlas_end;
-        base = 0u;
-      } else {
-        searching = false;
-      }
-    }
-    // ---- one node step
-    if (searching) {
-      const f4 lo = M.nodes[2 * curr], hi = M.nodes[2 * curr + 1];
-      if (DETAIL) n_nodes++;
-      const bool hit = hit_box4(lo, hi, r, RT_T_MIN, closest);
-      const uint32_t data = rt_f2u(hi.w);
-      const bool leafhit = hit && data != 0u;
-      uint32_t next = (hit && data == 0u) ? curr + 1u : base + rt_f2u(lo.w);
-      const bool got_leaf = leafhit && in_blas;
-      if (leafhit && !in_blas) {
-        cur_inst = data >> 3;
-        uint32_t off;
-        r = to_instance(M, cur_inst, o, d, off);
-        tlas_next = next;
-        base = blas_base + off;
-        end = base + rt_f2u(M.nodes[2 * base].w);
-        next = base;
-        in_blas = true;
-      }
-      leaf = got_leaf ? data : leaf;
-      waiting = got_leaf;
-      searching = !got_leaf;
-      curr = next;
-    }
-    // ---- flush the triangle queue?
-    const unsigned long long smask = __ballot(searching);
-    const unsigned long long wmask = __ballot(waiting);
-    const uint32_t cntl = waiting ? (leaf & 7u) : 0u;
-    const unsigned long long b0 = __ballot((cntl & 1u) != 0u), b1 = __ballot((cntl & 2u) != 0u), b2 = __ballot((cntl & 4u) != 0u);
-    const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
-                           4u * (uint32_t)__builtin_popcountll(b2);
-    if (wmask != 0ull && (total >= RT_FLUSH_ITEMS || smask == 0ull)) {
-      const uint32_t excl =
-          __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-          2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
-          4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
-      const uint32_t first = leaf >> 3;
-      if (waiting) {
-        f4 ra, rb;
-        ra.x = r.o.x; ra.y = r.o.y; ra.z = r.o.z; ra.w = RT_T_MIN;
-        rb.x = r.d.x; rb.y = r.d.y; rb.z = r.d.z; rb.w = closest;
-        W.rays[2 * lane] = ra;
-        W.rays[2 * lane + 1] = rb;
-        const uint32_t tag = lane << 26;
-#pragma unroll
-        for (uint32_t i = 0; i < 7u; i++)
-          if (i < cntl) W.items[excl + i] = tag | (first + i);
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t c = 0; c < total; c += 64u) {
-        const uint32_t j = c + lane;
-        if (j < total) {
-          const uint32_t it = W.items[j];
-          const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
-          f4 ra = W.rays[2 * owner], rb = W.rays[2 * owner + 1];
-          LocalRay q;
-          q.o = rt3_make(ra.x, ra.y, ra.z);
-          q.d = rt3_make(rb.x, rb.y, rb.z);
-          float t;
-          bool ok = hit_tri_nb(M.tri_geom[3 * tri], M.tri_geom[3 * tri + 1], M.tri_geom[3 * tri + 2], q, ra.w, rb.w, t);
-          W.items[j] = rt_f2u(ok ? t : -1.0f);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (waiting) {
-        bool stop = false;
-#pragma unroll
-        for (uint32_t i = 0; i < 7u; i++) {
-          if (i < cntl && !stop) {
-            if (DETAIL) n_tris++;
-            const float t = rt_u2f(W.items[excl + i]);
-            if (t > 0.0f && t < closest) {
-              if (ANY) {
-                any = true;
-                stop = true;
-              } else {
-                closest = t;
-                best_tri = (int32_t)(first + i);
-                best_inst = (int32_t)cur_inst;
-              }
-            }
-          }
-        }
-        waiting = false;
-        searching = !stop;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+    trav_step<DETAIL, MODE>(M, s_scene, s, n_nodes);
+    trav_flush<ANY, DETAIL, MODE>(M, s_scene, W, s, n_tris);
   }
   if (!ANY) wq_finish(wq_next, next_active);
   LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
-  flush_counters<DETAIL>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
 }
 
 // Ordered accumulation of a batched dispatch: acc = (frame_count > 1 ? acc : 0) + (col_f, 1) for f = 0..n-1, the

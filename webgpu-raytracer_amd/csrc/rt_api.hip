@@ -54,7 +54,11 @@ struct rt_ctx {
   DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, inst_trav, light_rec;
-  bool tris_dirty = true, inst_dirty = true, lights_dirty = true;
+  DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w;   // k_treelet.hip.h
+  std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
+  bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true;
+  int wf_block = 0;              // threads per workgroup of the wavefront trace kernels (0 = default; MI355RT_WF_BLOCK)
+  size_t lds_per_cu = 160 * 1024;
   bool validate_dirty = true, scene_valid = false;  // k_validate_scene: run once per upload
   std::string scene_problem;
   std::vector<uint32_t> blas_roots;                 // sorted unique BLAS-local root offsets of the instances
@@ -86,7 +90,8 @@ struct rt_ctx {
   int occ_blocks[4] = {0, 0, 0, 0};   // cached occupancy query per persistent-kernel variant
   int wf_occ_blocks[2] = {0, 0};      // ... and for the two wavefront trace kernels
   size_t wf_occ_dyn = (size_t)-1;
-  int wf_occ_detail = -1;
+  int wf_occ_detail = -1, wf_occ_block = 0;
+  int wf_blocks_per_cu = 0;      // 0 = default for the block size (MI355RT_WF_BLOCKS_PER_CU)
   size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
@@ -273,6 +278,38 @@ int prepare_scene(rt_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     c->inst_dirty = false;
   }
+  if (c->nodes_dirty && c->n_nodes && c->n_instances) {
+    // traversal copy of the node array: explicit successors, most-visited nodes first (k_treelet.hip.h); validate_scene
+    // has just uploaded the sorted BLAS roots into val_roots and vouches for every pointer followed here
+    int r = ensure_buffer(c, c->tnodes, (size_t)c->n_nodes * 32, true);
+    if (r < 0) return r;
+    if ((r = ensure_buffer(c, c->node_key, (size_t)c->n_nodes * 4, true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->node_newidx, (size_t)c->n_nodes * 4, true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->inst_root, (size_t)c->n_instances * 4, true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->root_w, std::max<size_t>(4, c->root_w_host.size() * 4), true)) < 0) return r;
+    if (!c->root_w_host.empty())
+      HIP_TRY(c, hipMemcpyAsync(c->root_w.ptr, c->root_w_host.data(), c->root_w_host.size() * 4, hipMemcpyHostToDevice, c->stream));
+    rtk::TreeletArgs T;
+    T.nodes = (const float4*)c->nodes.ptr;
+    T.tnodes = (float4*)c->tnodes.ptr;
+    T.key = (uint32_t*)c->node_key.ptr;
+    T.new_index = (uint32_t*)c->node_newidx.ptr;
+    T.roots = (const uint32_t*)c->val_roots.ptr;
+    T.root_w = (const float*)c->root_w.ptr;
+    T.n_nodes = c->n_nodes;
+    T.n_tlas = c->blas_offset;
+    T.n_roots = (uint32_t)c->blas_roots.size();
+    T.k_max = (uint32_t)(c->lds_per_cu / 32);
+    const dim3 grid((c->n_nodes + 255) / 256);
+    hipLaunchKernelGGL(rtk::k_treelet_weight, grid, dim3(256), 0, c->stream, T);
+    hipLaunchKernelGGL(rtk::k_treelet_order, dim3(1), dim3(1024), 0, c->stream, T);
+    hipLaunchKernelGGL(rtk::k_treelet_remap, grid, dim3(256), 0, c->stream, T);
+    hipLaunchKernelGGL(rtk::k_treelet_inst_roots, dim3((c->n_instances + 255) / 256), dim3(256), 0, c->stream,
+                       (const float4*)c->instances.ptr, (const uint32_t*)c->node_newidx.ptr, (uint32_t*)c->inst_root.ptr,
+                       c->n_instances, c->blas_offset, c->n_nodes);
+    HIP_TRY(c, hipGetLastError());
+    c->nodes_dirty = false;
+  }
   if (c->lights_dirty && c->n_lights && c->n_tris && c->n_instances && c->n_verts) {
     int r = ensure_buffer(c, c->light_rec, (size_t)c->n_lights * 64, true);
     if (r < 0) return r;
@@ -295,6 +332,8 @@ bool scene_ready(const rt_ctx* c) {
 DevScene dev_scene(const rt_ctx* c) {
   DevScene s;
   s.nodes = (const float4*)c->nodes.ptr;
+  s.tnodes = (const float4*)c->tnodes.ptr;
+  s.inst_root = (const uint32_t*)c->inst_root.ptr;
   s.tri_geom = (const float4*)c->tri_geom.ptr;
   s.inst_trav = (const float4*)c->inst_trav.ptr;
   s.topo = (const float4*)c->topology.ptr;
@@ -366,6 +405,14 @@ rt_ctx* rt_create(int device_ordinal) {
     return nullptr;
   }
   c->stream = c->own_stream;
+  if (const char* e = getenv("MI355RT_WF_BLOCK")) {
+    const int b = atoi(e);
+    if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
+  }
+  if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
+    const int b = atoi(e);
+    if (b >= 1 && b <= 8) c->wf_blocks_per_cu = b;
+  }
   // counters: 2 banks (primary kernel, path-trace kernel) x RT_COUNTER_SHARDS x 6 u64
   if (hipMalloc(&c->counters.ptr, 2 * RT_COUNTER_SHARDS * 6 * sizeof(uint64_t)) != hipSuccess) {
     g_create_error = "hipMalloc(counters) failed";
@@ -399,7 +446,8 @@ void rt_destroy(rt_ctx* c) {
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
-                         &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad};
+                         &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
+                         &c->inst_root, &c->root_w};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -714,7 +762,21 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
         for (uint32_t k = 0; k < c->n_instances; k++) c->blas_roots[k] = hi[k].blas_node_offset;
         std::sort(c->blas_roots.begin(), c->blas_roots.end());
         c->blas_roots.erase(std::unique(c->blas_roots.begin(), c->blas_roots.end()), c->blas_roots.end());
+        // visit-probability weight of each BLAS for the treelet order: sum over its instances of the squared linear
+        // scale, |det(M3x3)|^(2/3) (object-space box areas times this approximate world-space areas)
+        c->root_w_host.assign(c->blas_roots.size(), 0.0f);
+        for (uint32_t k = 0; k < c->n_instances; k++) {
+          const float* m = hi[k].transform;   // column-major 4x4
+          const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[6] * m[9]) -
+                             (double)m[4] * ((double)m[1] * m[10] - (double)m[2] * m[9]) +
+                             (double)m[8] * ((double)m[1] * m[6] - (double)m[2] * m[5]);
+          double s2 = std::pow(std::fabs(det), 2.0 / 3.0);
+          if (!(s2 > 0.0) || !std::isfinite(s2)) s2 = 1.0;
+          const size_t r = std::lower_bound(c->blas_roots.begin(), c->blas_roots.end(), hi[k].blas_node_offset) - c->blas_roots.begin();
+          c->root_w_host[r] += (float)s2;
+        }
       }
+      c->nodes_dirty = true;
       c->validate_dirty = true;
       c->inst_dirty = true;
       c->lights_dirty = true;
@@ -783,6 +845,7 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
   c->blas_offset = n_tlas;  // this.blasOffset = tlas.length / 8
   c->n_nodes = n_tlas + n_blas;
   c->validate_dirty = true;
+  c->nodes_dirty = true;
   return r ? RT_REALLOCATED : RT_OK;
 }
 
@@ -798,6 +861,44 @@ int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32
 }
 
 int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
+
+// What one workgroup stages in LDS behind its wave queues, given `budget` bytes of LDS per workgroup: as many of the
+// first (most visited) tnodes as fit, then the triangle records and the instance rows + BLAS roots if they fit whole.
+// *dyn_bytes = dynamic LDS size of the launch.
+static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes, size_t* dyn_bytes) {
+  rtk::LdsPlan P;
+  P.k_nodes = P.stage_inst = P.stage_tri = P.pad = 0;
+  budget &= ~(size_t)2047;   // LDS is allocated in granules: leave room so that the intended number of workgroups fits a CU
+  size_t avail = budget > queue_bytes ? budget - queue_bytes : 0;
+  avail &= ~(size_t)15;
+  size_t k = std::min<size_t>(c->n_nodes, avail / 32);
+  P.k_nodes = (uint32_t)k;
+  avail -= k * 32;
+  const size_t tri_bytes = (size_t)c->n_tris * 48;
+  if (tri_bytes <= avail) {
+    P.stage_tri = 1;
+    avail -= tri_bytes;
+  }
+  const size_t inst_bytes = (size_t)c->n_instances * 64 + (((size_t)c->n_instances + 3) / 4) * 16;
+  if (inst_bytes <= avail) {
+    P.stage_inst = 1;
+    avail -= inst_bytes;
+  }
+  *dyn_bytes = queue_bytes + (size_t)P.k_nodes * 32 + (P.stage_tri ? tri_bytes : 0) + (P.stage_inst ? inst_bytes : 0);
+  return P;
+}
+
+extern "C++" {
+template <int BLOCK>
+static const void* wf_trace_fn(bool any, bool detail, bool lds) {
+  if (any) {
+    if (detail) return lds ? (const void*)rtk::k_wf_trace<true, true, true, BLOCK> : (const void*)rtk::k_wf_trace<true, true, false, BLOCK>;
+    return lds ? (const void*)rtk::k_wf_trace<true, false, true, BLOCK> : (const void*)rtk::k_wf_trace<true, false, false, BLOCK>;
+  }
+  if (detail) return lds ? (const void*)rtk::k_wf_trace<false, true, true, BLOCK> : (const void*)rtk::k_wf_trace<false, true, false, BLOCK>;
+  return lds ? (const void*)rtk::k_wf_trace<false, false, true, BLOCK> : (const void*)rtk::k_wf_trace<false, false, false, BLOCK>;
+}
+}  // extern "C++"
 
 // Wavefront form: per depth one shade launch and two trace launches, all enqueued without host readback.
 static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, const DevFrameSlot* dslots, uint32_t n,
@@ -827,25 +928,37 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   Q.counters = (uint32_t*)c->wf_counters.ptr;
 
   const bool detail = c->detailed_counters;
-  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances) * 16;
+  // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
+  // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
+  // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
+  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
   const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
-  const size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + (trace_lds ? lds_records : 0);
-  const void* trace_fn[2];
-  if (detail) {
-    trace_fn[0] = trace_lds ? (const void*)rtk::k_wf_trace<true, true, true> : (const void*)rtk::k_wf_trace<true, true, false>;
-    trace_fn[1] = trace_lds ? (const void*)rtk::k_wf_trace<false, true, true> : (const void*)rtk::k_wf_trace<false, true, false>;
-  } else {
-    trace_fn[0] = trace_lds ? (const void*)rtk::k_wf_trace<true, false, true> : (const void*)rtk::k_wf_trace<true, false, false>;
-    trace_fn[1] = trace_lds ? (const void*)rtk::k_wf_trace<false, false, true> : (const void*)rtk::k_wf_trace<false, false, false>;
+  int block = 256, blocks_per_cu = 0;
+  if (!trace_lds) {
+    block = c->wf_block ? c->wf_block : 1024;
+    blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : (block == 1024 ? 1 : (block == 512 ? 2 : 6));
   }
-  if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_blocks[0] == 0) {
+  const size_t queue_bytes = (size_t)(block / 64) * RT_WORK_BYTES_PER_WAVE;
+  size_t dyn = queue_bytes + lds_records;
+  rtk::LdsPlan plan;
+  plan.k_nodes = c->n_nodes;
+  plan.stage_inst = plan.stage_tri = 1;
+  plan.pad = 0;
+  if (!trace_lds) plan = plan_lds(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+  const void* trace_fn[2];
+  for (int k = 0; k < 2; k++)
+    trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds)
+                                : (block == 512 ? wf_trace_fn<512>(k == 0, detail, trace_lds) : wf_trace_fn<256>(k == 0, detail, trace_lds));
+  if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_blocks[0] == 0) {
     for (int k = 0; k < 2; k++) {
+      HIP_TRY(c, hipFuncSetAttribute(trace_fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
       int per_cu = 0;
-      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], 256, dyn));
+      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], block, dyn));
       c->wf_occ_blocks[k] = per_cu < 1 ? 1 : per_cu;
     }
     c->wf_occ_dyn = dyn;
     c->wf_occ_detail = (int)detail;
+    c->wf_occ_block = block;
   }
   uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
   const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * 16);
@@ -868,15 +981,15 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
     for (int k = 0; k < 2; k++) {
       uint32_t blocks = (uint32_t)c->wf_occ_blocks[k] * (uint32_t)c->num_cus;
-      const uint32_t max_useful = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)0x7fffffff);
+      const uint32_t max_useful = (uint32_t)std::min<size_t>((items + (size_t)block - 1) / (size_t)block, (size_t)0x7fffffff);
       if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
       DevScene Sa = S;
       DevFrame Fa = F;
       rt_scene_uniforms Ua = c->uniforms;
-      void* args[] = {&Sa, &Fa, &Ua, &W, &Q, &depth, &nn, &nt, &ni};
+      void* args[] = {&Sa, &Fa, &Ua, &W, &Q, &depth, &nn, &nt, &ni, &plan};
       EventPair* evt = next_events(c, k == 0 ? RT_TIMER_WF_TRACE_SHADOW : RT_TIMER_WF_TRACE_EXT);
       if (evt) HIP_TRY(c, hipEventRecord(evt->a, c->stream));
-      HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(256), args, dyn, c->stream));
+      HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(block), args, dyn, c->stream));
       if (evt) HIP_TRY(c, hipEventRecord(evt->b, c->stream));
     }
   }
@@ -1023,7 +1136,14 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->ticket.ptr, 0, 4, c->stream));
     const size_t lds_bytes = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
     const bool use_lds = lds_bytes + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
-    const size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + (use_lds ? lds_bytes : 0);  // work queues + records
+    size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + lds_bytes;  // work queues + records
+    rtk::LdsPlan plan;
+    plan.k_nodes = c->n_nodes;
+    plan.stage_inst = plan.stage_tri = 1;
+    plan.pad = 0;
+    // a scene that does not fit as a whole: six 256-thread workgroups per CU (6 waves / SIMD), each with its share of the
+    // CU's LDS for the top of the tree
+    if (!use_lds) plan = plan_lds(c, c->lds_per_cu / 6, (size_t)4 * RT_WORK_BYTES_PER_WAVE, &dyn);
     const int vi = (c->detailed_counters ? 2 : 0) + (use_lds ? 1 : 0);
     static const void* const fns[4] = {(const void*)rtk::k_pathtrace_persistent<false, false>,
                                        (const void*)rtk::k_pathtrace_persistent<false, true>,
@@ -1033,6 +1153,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     // resident workgroups per CU: queried once per (variant, LDS size)
     if (c->occ_dyn[vi] != dyn || c->occ_blocks[vi] == 0) {
       int per_cu = 0;
+      HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
       HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn));
       c->occ_blocks[vi] = per_cu < 1 ? 1 : per_cu;
       c->occ_dyn[vi] = dyn;
@@ -1044,7 +1165,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     uint32_t* ticket = (uint32_t*)c->ticket.ptr;
     uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts, ns = n;
-    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv, &dslots, &ns};
+    void* args[] = {&S, &F, &c->uniforms, &ticket, &nn, &nt, &ni, &nv, &dslots, &ns, &plan};
     ev = next_events(c, RT_TIMER_PATHTRACE);
     if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     HIP_TRY(c, hipLaunchKernel(fn, dim3(blocks), dim3(256), args, dyn, c->stream));
