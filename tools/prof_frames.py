@@ -36,7 +36,7 @@ r.compute(1)
 r.sync()
 r.resetCounters()
 r.setKernelTiming(True)
-r.kernelTimeMs()
+r.kernelTimes()
 t0 = time.perf_counter()
 fl = list(range(2, frames + 2))
 if batch > 1:
@@ -47,12 +47,15 @@ else:
         r.compute(f)
 r.sync()
 dt = time.perf_counter() - t0
-k = r.kernelTimeMs()
+kt = r.kernelTimes()
+k = {"pathtrace_ms": kt["pathtrace"]["ms"] / max(1, kt["pathtrace"]["launches"]),
+     "primary_ms": kt["primary"]["ms"] / max(1, kt["primary"]["launches"])}
 c = r.getCounters()
 rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
 print("scene=%s %dx%d frames=%d depth=%d variant=%d: %.3f ms/frame wall, pathtrace %.4f ms, primary %.4f ms, "
       "%.1f Mrays/frame, %.1f Mrays/s" % (scene, w, h, frames, depth, variant, dt / frames * 1e3, k["pathtrace_ms"],
                                           k["primary_ms"], rays / frames / 1e6, rays / dt / 1e6))
+print("kernel ms (sum over the run):", {kk: round(vv["ms"], 2) for kk, vv in kt.items() if vv["launches"]})
 print({kk: vv // frames for kk, vv in c.items()})
 if detailed:
     print("pathtrace kernel only:", {kk: vv // frames for kk, vv in r.getKernelCounters(1).items()})

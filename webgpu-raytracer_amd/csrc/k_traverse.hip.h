@@ -8,6 +8,24 @@ namespace rtk {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Loads with the address space spelled out.  HIP pointers are generic; when the same value can come from LDS or from
+// global memory the compiler otherwise merges the two loads into ONE flat_load behind a pointer select — a flat access
+// pays the address-space check per lane and waits on both vmcnt and lgkmcnt.
+typedef const f4 __attribute__((address_space(1))) * rt_gptr;
+typedef const f4 __attribute__((address_space(3))) * rt_lptr;
+typedef const uint32_t __attribute__((address_space(1))) * rt_gptr32;
+typedef const uint32_t __attribute__((address_space(3))) * rt_lptr32;
+__device__ __forceinline__ f4 ld_g(const f4* p, size_t i) { return ((rt_gptr)p)[i]; }
+__device__ __forceinline__ f4 ld_l(const f4* p, uint32_t i) { return ((rt_lptr)p)[i]; }
+__device__ __forceinline__ uint32_t ld_g32(const uint32_t* p, size_t i) { return ((rt_gptr32)p)[i]; }
+__device__ __forceinline__ uint32_t ld_l32(const void* p, uint32_t i) { return ((rt_lptr32)p)[i]; }
+// opaque copy of a register value: keeps the optimiser from re-reading adjacent struct fields as one vector load from
+// a stack slot (which forced the ray of every lane through scratch memory)
+__device__ __forceinline__ float rt_opaque(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // Where the traversal records live.  `tnodes` (k_treelet.hip.h) has its first k_lds nodes staged in LDS at slot l_nodes
 // of the workgroup's dynamic LDS array; the triangle records, the instance rows and the instance BLAS roots are staged
 // as a whole when they fit (l_* != RT_LDS_NONE), else read through L1 / L2.  Slots are 16-byte units.
@@ -28,11 +46,11 @@ enum { RT_TRAV_LDS = 1, RT_TRAV_MIXED = 2 };
 template <int MODE>
 __device__ __forceinline__ void trav_fetch_node(const TravMem& M, const f4* lds, uint32_t idx, f4& lo, f4& hi) {
   if (MODE == RT_TRAV_LDS || idx < M.k_lds) {
-    lo = lds[M.l_nodes + 2u * idx];
-    hi = lds[M.l_nodes + 2u * idx + 1u];
+    lo = ld_l(lds, M.l_nodes + 2u * idx);
+    hi = ld_l(lds, M.l_nodes + 2u * idx + 1u);
   } else {
-    lo = M.gnodes[2 * (size_t)idx];
-    hi = M.gnodes[2 * (size_t)idx + 1];
+    lo = ld_g(M.gnodes, 2 * (size_t)idx);
+    hi = ld_g(M.gnodes, 2 * (size_t)idx + 1);
   }
 }
 
@@ -53,15 +71,15 @@ __device__ __forceinline__ LocalRay to_instance(const TravMem& M, const f4* lds,
                                                 uint32_t& blas_root) {
   f4 r0, r1, r2;
   if (MODE == RT_TRAV_LDS || M.l_inst != RT_LDS_NONE) {
-    r0 = lds[M.l_inst + 4u * inst + 0u];
-    r1 = lds[M.l_inst + 4u * inst + 1u];
-    r2 = lds[M.l_inst + 4u * inst + 2u];
-    blas_root = reinterpret_cast<const uint32_t*>(lds + M.l_root)[inst];
+    r0 = ld_l(lds, M.l_inst + 4u * inst + 0u);
+    r1 = ld_l(lds, M.l_inst + 4u * inst + 1u);
+    r2 = ld_l(lds, M.l_inst + 4u * inst + 2u);
+    blas_root = ld_l32(lds + M.l_root, inst);
   } else {
-    r0 = M.ginst[4 * (size_t)inst + 0];
-    r1 = M.ginst[4 * (size_t)inst + 1];
-    r2 = M.ginst[4 * (size_t)inst + 2];
-    blas_root = M.groot[inst];
+    r0 = ld_g(M.ginst, 4 * (size_t)inst + 0);
+    r1 = ld_g(M.ginst, 4 * (size_t)inst + 1);
+    r2 = ld_g(M.ginst, 4 * (size_t)inst + 2);
+    blas_root = ld_g32(M.groot, inst);
   }
   rt3 lo = rt3_make(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w * 1.0f, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w * 1.0f,
                     r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w * 1.0f);
@@ -204,8 +222,8 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
   const uint32_t first = s.leaf >> 3;
   if (s.waiting) {
     f4 ra, rb;
-    ra.x = s.r.o.x; ra.y = s.r.o.y; ra.z = s.r.o.z; ra.w = s.t_min;
-    rb.x = s.r.d.x; rb.y = s.r.d.y; rb.z = s.r.d.z; rb.w = s.closest;
+    ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = s.t_min;
+    rb.x = rt_opaque(s.r.d.x); rb.y = rt_opaque(s.r.d.y); rb.z = rt_opaque(s.r.d.z); rb.w = s.closest;
     W.rays[2 * lane] = ra;
     W.rays[2 * lane + 1] = rb;
     const uint32_t tag = lane << 26;
@@ -226,13 +244,13 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
       q.d = rt3_make(rb.x, rb.y, rb.z);
       f4 g0, g1, g2;
       if (tri_lds) {
-        g0 = lds[M.l_tri + 3u * tri];
-        g1 = lds[M.l_tri + 3u * tri + 1u];
-        g2 = lds[M.l_tri + 3u * tri + 2u];
+        g0 = ld_l(lds, M.l_tri + 3u * tri);
+        g1 = ld_l(lds, M.l_tri + 3u * tri + 1u);
+        g2 = ld_l(lds, M.l_tri + 3u * tri + 2u);
       } else {
-        g0 = M.gtri[3 * (size_t)tri];
-        g1 = M.gtri[3 * (size_t)tri + 1];
-        g2 = M.gtri[3 * (size_t)tri + 2];
+        g0 = ld_g(M.gtri, 3 * (size_t)tri);
+        g1 = ld_g(M.gtri, 3 * (size_t)tri + 1);
+        g2 = ld_g(M.gtri, 3 * (size_t)tri + 2);
       }
       float t;
       bool ok = hit_tri_nb(g0, g1, g2, q, ra.w, rb.w, t);
