@@ -182,8 +182,7 @@ enum {
   RT_TIMER_WF_TRACE_SHADOW = 3, /* k_wf_trace<any hit>                                                     */
   RT_TIMER_WF_TRACE_EXT = 4,    /* k_wf_trace<closest hit>                                                 */
   RT_TIMER_POST = 5,            /* k_postprocess                                                           */
-  RT_TIMER_WF_SORT = 6,         /* k_sort_hist + k_sort_scan + k_sort_scatter of one ray queue             */
-  RT_TIMER_COUNT = 7
+  RT_TIMER_COUNT = 6
 };
 int rt_kernel_times(rt_ctx* ctx, double* sum_ms, uint32_t* launches, uint32_t n);
 /* Diagnostic build (-DRT_CLOCK_STAMP) only: {delta s_memtime, delta s_memrealtime} of each workgroup of the last

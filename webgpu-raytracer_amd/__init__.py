@@ -9,10 +9,10 @@ repo root) or through importlib.
 from . import _build
 from .world_bridge import WorldBridge
 from .renderer import WebGPURenderer, RendererError, upload_scene, sync_world, LiveLoop
-from .recorder import FrameLoop
+from .recorder import FrameLoop, FrameJobRunner, job_list, write_png
 from . import textures
 
-__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "sync_world", "LiveLoop", "FrameLoop", "textures", "build"]
+__all__ = ["WebGPURenderer", "WorldBridge", "RendererError", "upload_scene", "sync_world", "LiveLoop", "FrameLoop", "FrameJobRunner", "job_list", "write_png", "textures", "build"]
 
 
 def build(force=False):

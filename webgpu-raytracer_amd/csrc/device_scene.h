@@ -86,13 +86,6 @@ struct WfQueues {
   float4* shadow_rays;    // ... and {o.xyz, t_max} {d.xyz, 0}
   uint32_t* ext_ids;      // extension-ray queue (the ray is the path's ro / rd)
   uint32_t* counters;     // 8 u32 per depth: n_active, n_shadow, n_ext, head_shadow, head_ext, 0, 0, 0
-  // coherence binning (k_raysort.hip.h); sort == 0: the trace kernels pull the queues as the shade kernel wrote them
-  uint32_t* shadow_keys;  // one key per queue slot
-  uint32_t* ext_keys;
-  uint32_t* shadow_sorted;  // queue slots of the shadow rays in key order
-  uint32_t* ext_sorted;     // path ids of the extension rays in key order
-  uint32_t* sort_hist;      // per depth: 2 x (RT_SORT_BINS + 1) words, [..][RT_SORT_BINS] = rays in the queue
-  uint32_t sort;
 };
 #define WF_FLAG_SPECULAR 0x100u
 #define WF_FLAG_ENDED 0x200u

@@ -25,6 +25,7 @@ namespace rtk {
 // and then appends with ballot/mbcnt ranks (a queue counter is a single address: ~88 atomics/us chip-wide, so one atomic
 // per wave-append or per 16-ray pull caps a stage at a few Grays/s). Unused tail entries of a chunk hold RT_WF_INVALID.
 #define RT_WF_CHUNK 256u
+#define RT_WF_INVALID 0xffffffffu
 struct WaveQueueWriter {
   uint32_t pos, end;  // wave-uniform cursor into the current chunk
 };
@@ -71,15 +72,6 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
   const uint32_t* active_in = Q.active[depth & 1u];
   uint32_t cnt_shaded = 0;
   WaveQueueWriter wq_shadow = {0u, 0u}, wq_ext = {0u, 0u};
-  // scene box for the coherence keys: the TLAS root (node 0 of tnodes)
-  rt3 box_lo = rt3_splat(0.0f), box_scale = rt3_splat(0.0f);
-  if (Q.sort) {
-    const float4 blo = S.tnodes[0], bhi = S.tnodes[1];
-    box_lo = xyz(blo);
-    const rt3 ext = xyz(bhi) - xyz(blo);
-    box_scale = rt3_make(ext.x > 0.0f ? 16.0f / ext.x : 0.0f, ext.y > 0.0f ? 16.0f / ext.y : 0.0f,
-                         ext.z > 0.0f ? 16.0f / ext.z : 0.0f);
-  }
   // wave-uniform loop (every lane of a wave takes part in the queue appends)
   for (uint32_t base_idx = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base_idx < count; base_idx += gridDim.x * 256u) {
     const uint32_t idx = base_idx + (threadIdx.x & 63u);
@@ -169,13 +161,9 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
       Q.shadow_ids[sslot] = id;
       Q.shadow_rays[2 * sslot] = make_float4(bo.sh_o.x, bo.sh_o.y, bo.sh_o.z, bo.sh_tmax);
       Q.shadow_rays[2 * sslot + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
-      if (Q.sort) Q.shadow_keys[sslot] = ray_sort_key(box_lo, box_scale, bo.sh_o, bo.sh_d);
     }
     const uint32_t eslot = wq_append(wq_ext, &cnt[2], Q.ext_ids, live && bo.want_extend);
-    if (eslot != RT_WF_INVALID) {
-      Q.ext_ids[eslot] = id;
-      if (Q.sort) Q.ext_keys[eslot] = ray_sort_key(box_lo, box_scale, p.ro, p.rd);
-    }
+    if (eslot != RT_WF_INVALID) Q.ext_ids[eslot] = id;
     if (live) {
       if (bo.ended && !bo.want_shadow) {
         F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
@@ -229,8 +217,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t blas_base = U.blas_base_idx;
   uint32_t* cnt = Q.counters + 8u * depth;
-  const uint32_t* sort_hist = Q.sort_hist + (size_t)(2u * depth + (ANY ? 0u : 1u)) * (RT_SORT_BINS + 1u);
-  const uint32_t n_rays = Q.sort ? sort_hist[RT_SORT_BINS] : (ANY ? cnt[1] : cnt[2]);
+  const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
   uint32_t* head = ANY ? &cnt[3] : &cnt[4];
   uint32_t* next_active = Q.active[(depth + 1u) & 1u];
   uint32_t* next_count = Q.counters + 8u * (depth + 1u);
@@ -315,15 +302,13 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
           const uint32_t qi = chunk_pos + rank;
           chunk_pos += (uint32_t)__builtin_popcountll(need_m);
           if (need && qi < chunk_end) {
-            // binned queues: the sorted list names the queue slot (shadow rays) or the path (extension rays)
-            const uint32_t qs = (Q.sort && ANY) ? Q.shadow_sorted[qi] : qi;
-            const uint32_t rid = ANY ? Q.shadow_ids[qs] : (Q.sort ? Q.ext_sorted[qi] : Q.ext_ids[qi]);
+            const uint32_t rid = ANY ? Q.shadow_ids[qi] : Q.ext_ids[qi];
             if (rid != RT_WF_INVALID) {
               id = rid;
               rt3 o, d;
               float t_max;
               if (ANY) {
-                const float4 r0 = Q.shadow_rays[2 * qs], r1 = Q.shadow_rays[2 * qs + 1];
+                const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
                 o = xyz(r0);
                 d = xyz(r1);
                 t_max = r0.w;

@@ -9,7 +9,6 @@
 //   k_treelet.hip.h           upload-time re-layout of the node array: explicit successors, most-visited nodes first
 //   k_traverse.hip.h          the wave-level TLAS / BLAS walk (node step + LDS triangle queue), one copy for both forms
 //   k_pathtrace.hip.h         Raytracer.wgsl `main` + ray_color (:607-819): k_pathtrace, k_pathtrace_persistent
-//   k_raysort.hip.h           counting sort of the wavefront form's ray queues by origin cell and direction octant
 //   k_wavefront.hip.h         the same bounce as shade / trace stages over device queues (large scenes)
 //   k_texture_post.hip.h      k_resize_texture; k_postprocess = PostProcess.wgsl `main` (:103-176)
 //   k_validate.hip.h          k_validate_scene: every index the kernels follow, checked once per upload
@@ -33,7 +32,6 @@
 #include "k_treelet.hip.h"
 #include "k_traverse.hip.h"
 #include "k_pathtrace.hip.h"
-#include "k_raysort.hip.h"
 #include "k_wavefront.hip.h"
 #include "k_texture_post.hip.h"
 #include "k_validate.hip.h"

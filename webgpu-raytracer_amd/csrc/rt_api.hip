@@ -105,9 +105,6 @@ struct rt_ctx {
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
   DeviceBuffer frame_col;   // per-frame colours of a batch, added in frame order by k_accumulate_frames
   DeviceBuffer wf_state, wf_queues, wf_counters;  // wavefront form: path state, ray / path queues, queue counters
-  DeviceBuffer wf_sort;          // coherence binning of the ray queues: keys, sorted lists, histograms, cursors
-  int wf_sort_mode = -1;         // -1 = auto (on for scenes whose records do not fit LDS), 0 = off, 1 = on (MI355RT_WF_SORT)
-  bool sort_lds_set = false;
 
   // kernel timing
   bool timing = false;
@@ -412,7 +409,6 @@ rt_ctx* rt_create(int device_ordinal) {
     const int b = atoi(e);
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
   }
-  if (const char* e = getenv("MI355RT_WF_SORT")) c->wf_sort_mode = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
     const int b = atoi(e);
     if (b >= 1 && b <= 8) c->wf_blocks_per_cu = b;
@@ -448,7 +444,7 @@ void rt_destroy(rt_ctx* c) {
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
                          &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
-                         &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters, &c->wf_sort,
+                         &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
                          &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
                          &c->inst_root, &c->root_w};
@@ -930,32 +926,6 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   Q.shadow_ids = (uint32_t*)(qb + qcap * 40);
   Q.ext_ids = (uint32_t*)(qb + qcap * 44);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
-  const uint32_t depths_q = c->max_depth ? c->max_depth : 1u;
-  // coherence binning of the ray queues before every trace stage (k_raysort.hip.h): pays where the walk reads through
-  // L1 / L2, not for an LDS-resident scene
-  const bool sort = c->wf_sort_mode == 1 || (c->wf_sort_mode < 0 && !fits_lds);
-  Q.sort = sort ? 1u : 0u;
-  Q.shadow_keys = Q.ext_keys = Q.shadow_sorted = Q.ext_sorted = Q.sort_hist = nullptr;
-  uint32_t* sort_cursor = nullptr;
-  const size_t hist_words = (size_t)depths_q * 2 * (RT_SORT_BINS + 1);
-  if (sort) {
-    r = ensure_buffer(c, c->wf_sort, qcap * 16 + (hist_words + RT_SORT_BINS) * 4, false);
-    if (r < 0) return r;
-    char* sb = (char*)c->wf_sort.ptr;
-    Q.shadow_keys = (uint32_t*)sb;
-    Q.ext_keys = (uint32_t*)(sb + qcap * 4);
-    Q.shadow_sorted = (uint32_t*)(sb + qcap * 8);
-    Q.ext_sorted = (uint32_t*)(sb + qcap * 12);
-    Q.sort_hist = (uint32_t*)(sb + qcap * 16);
-    sort_cursor = Q.sort_hist + hist_words;
-    HIP_TRY(c, hipMemsetAsync(Q.sort_hist, 0, hist_words * 4, c->stream));
-    if (!c->sort_lds_set) {
-      HIP_TRY(c, hipFuncSetAttribute((const void*)rtk::k_sort_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RT_SORT_BINS * 4)));
-      HIP_TRY(c, hipFuncSetAttribute((const void*)rtk::k_sort_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RT_SORT_BINS * 4)));
-      c->sort_lds_set = true;
-    }
-  }
-
   const bool detail = c->detailed_counters;
   // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
   // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
@@ -1009,22 +979,6 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     }
     if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
     for (int k = 0; k < 2; k++) {
-      if (sort) {
-        rtk::SortArgs SA;
-        SA.ids = k == 0 ? Q.shadow_ids : Q.ext_ids;
-        SA.keys = k == 0 ? Q.shadow_keys : Q.ext_keys;
-        SA.sorted = k == 0 ? Q.shadow_sorted : Q.ext_sorted;
-        SA.n_slots = Q.counters + 8u * depth + (k == 0 ? 1u : 2u);
-        SA.hist = Q.sort_hist + (size_t)(2u * depth + (uint32_t)k) * (RT_SORT_BINS + 1);
-        SA.cursor = sort_cursor;
-        SA.write_ids = k == 0 ? 0u : 1u;
-        EventPair* evq = next_events(c, RT_TIMER_WF_SORT);
-        if (evq) HIP_TRY(c, hipEventRecord(evq->a, c->stream));
-        hipLaunchKernelGGL(rtk::k_sort_hist, dim3(c->num_cus), dim3(RT_SORT_BLOCK), RT_SORT_BINS * 4, c->stream, SA);
-        hipLaunchKernelGGL(rtk::k_sort_scan, dim3(1), dim3(RT_SORT_BLOCK), 0, c->stream, SA);
-        hipLaunchKernelGGL(rtk::k_sort_scatter, dim3(c->num_cus), dim3(RT_SORT_BLOCK), RT_SORT_BINS * 4, c->stream, SA);
-        if (evq) HIP_TRY(c, hipEventRecord(evq->b, c->stream));
-      }
       uint32_t blocks = (uint32_t)c->wf_occ_blocks[k] * (uint32_t)c->num_cus;
       const uint32_t max_useful = (uint32_t)std::min<size_t>((items + (size_t)block - 1) / (size_t)block, (size_t)0x7fffffff);
       if (blocks > max_useful) blocks = max_useful ? max_useful : 1;

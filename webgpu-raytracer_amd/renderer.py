@@ -331,7 +331,7 @@ class WebGPURenderer:
         return {"pathtrace_ms": pt.value, "primary_ms": pv.value, "launches": n.value}
 
 
-TIMER_NAMES = ("primary", "pathtrace", "wf_shade", "wf_trace_shadow", "wf_trace_ext", "post", "wf_sort")
+TIMER_NAMES = ("primary", "pathtrace", "wf_shade", "wf_trace_shadow", "wf_trace_ext", "post")
 
 
 def _kernel_times(self):
