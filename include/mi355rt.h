@@ -189,6 +189,11 @@ int rt_kernel_times(rt_ctx* ctx, double* sum_ms, uint32_t* launches, uint32_t n)
  * k_pathtrace_persistent launch (in-kernel clock = ratio x 100 MHz).  Returns the number of pairs written, 0 in the
  * product build, where no stamp executes. */
 int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
+/* Diagnostic build (-DRT_TRACE_STAMPS) only: s_memtime cycles the waves of k_wf_trace spent in its three sections,
+ * summed over all launches since the last reset: out16[queue][k], queue 0 = closest hit, 1 = any hit; k = 0..2 cycles in
+ * {retire / pull, node step, triangle flush}, 3..5 how often each did work, 6 waves, 7 loop trips.  Returns 1 in the
+ * diagnostic build, 0 in the product build (where no stamp executes and the array stays zero). */
+int rt_debug_trace_sections(rt_ctx* ctx, uint64_t* out16, int reset);
 /* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
  *   3 = auto (default): wavefront form when the scene's records do not fit LDS, SPP == 1 and the dispatch carries
  *       >= 4 frames (rt_compute_batch); the persistent kernel otherwise

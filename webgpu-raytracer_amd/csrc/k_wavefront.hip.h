@@ -190,6 +190,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 6
 #endif
+// Diagnostic build only (-DRT_TRACE_STAMPS, tools/trace_sections.py): per-wave s_memtime cycles spent in the three
+// sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
+// triangle flush; [3..5] = how often each section did work; [6] = waves; [7] = loop trips.  Nothing else reads it.
+__device__ unsigned long long g_trace_sections[2][8];
 template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
 void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
@@ -232,7 +236,14 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
   WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
   uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
 
+#ifdef RT_TRACE_STAMPS
+  unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
+#endif
   for (;;) {
+#ifdef RT_TRACE_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    st_trips++;
+#endif
     // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
     const bool done = have_ray && !s.searching && !s.waiting;
     const bool idle = !have_ray || done;
@@ -241,6 +252,9 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
          (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+#ifdef RT_TRACE_STAMPS
+      st_cnt[0]++;
+#endif
       bool push_next = false;
       if (done) {
         if (ANY) {
@@ -327,9 +341,36 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
     }
     if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
 
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+    st_cyc[0] += st1 - st0;
+    if (__ballot(s.searching) != 0ull) st_cnt[1]++;
+#endif
     trav_step<DETAIL, MODE>(M, s_scene, s, n_nodes);
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    st_cyc[1] += st2 - st1;
+    const bool was_waiting = __ballot(s.waiting) != 0ull;
+#endif
     trav_flush<ANY, DETAIL, MODE>(M, s_scene, W, s, n_tris);
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    st_cyc[2] += __builtin_amdgcn_s_memtime() - st2;
+    if (was_waiting && __ballot(s.waiting) == 0ull) st_cnt[2]++;
+#endif
   }
+#ifdef RT_TRACE_STAMPS
+  if (lane == 0u) {
+    for (int k = 0; k < 3; k++) {
+      atomicAdd(&g_trace_sections[ANY ? 1 : 0][k], st_cyc[k]);
+      atomicAdd(&g_trace_sections[ANY ? 1 : 0][3 + k], st_cnt[k]);
+    }
+    atomicAdd(&g_trace_sections[ANY ? 1 : 0][6], 1ull);
+    atomicAdd(&g_trace_sections[ANY ? 1 : 0][7], st_trips);
+  }
+#endif
   if (!ANY) wq_finish(wq_next, next_active);
   LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
   flush_counters<DETAIL>(c, F.counters, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));

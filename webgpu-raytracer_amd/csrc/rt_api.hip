@@ -92,6 +92,7 @@ struct rt_ctx {
   size_t wf_occ_dyn = (size_t)-1;
   int wf_occ_detail = -1, wf_occ_block = 0;
   int wf_blocks_per_cu = 0;      // 0 = default for the block size (MI355RT_WF_BLOCKS_PER_CU)
+  long treelet_cap = -1;
   size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
@@ -409,6 +410,7 @@ rt_ctx* rt_create(int device_ordinal) {
     const int b = atoi(e);
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
   }
+  if (const char* e = getenv("MI355RT_TREELET_MAX")) c->treelet_cap = atol(e);
   if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
     const int b = atoi(e);
     if (b >= 1 && b <= 8) c->wf_blocks_per_cu = b;
@@ -872,6 +874,7 @@ static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes,
   size_t avail = budget > queue_bytes ? budget - queue_bytes : 0;
   avail &= ~(size_t)15;
   size_t k = std::min<size_t>(c->n_nodes, avail / 32);
+  if (c->treelet_cap >= 0) k = std::min<size_t>(k, (size_t)c->treelet_cap);   // MI355RT_TREELET_MAX (experiments)
   P.k_nodes = (uint32_t)k;
   avail -= k * 32;
   const size_t tri_bytes = (size_t)c->n_tris * 48;
@@ -1349,6 +1352,21 @@ int rt_set_kernel_timing(rt_ctx* c, int enabled) {
   if (!c) return RT_ERR_INVALID;
   c->timing = enabled != 0;
   return RT_OK;
+}
+int rt_debug_trace_sections(rt_ctx* c, uint64_t* out16, int reset) {
+  if (!c || !out16) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(rtk::g_trace_sections), 128, 0, hipMemcpyDeviceToHost));
+  if (reset) {
+    uint64_t zero[16] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_trace_sections), zero, 128, 0, hipMemcpyHostToDevice));
+  }
+#ifdef RT_TRACE_STAMPS
+  return 1;
+#else
+  return 0;
+#endif
 }
 int rt_debug_clock_stamps(rt_ctx* c, uint64_t* out_pairs, uint32_t cap_pairs) {
   if (!c || !out_pairs) return RT_ERR_INVALID;
