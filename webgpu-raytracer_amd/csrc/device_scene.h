@@ -75,7 +75,7 @@ struct WfPath {       // one 96-B record per (frame, pixel) item: after the firs
   float4 c;           // d: radiance.xyz, bitcast(flags): depth | specular << 8 | ended << 9 | nee_valid << 10
   float4 d;           // e: pending NEE term .xyz, bitcast(tri)
   float4 e;
-  uint32_t inst, pad[3];
+  uint4 m;            // m: instance of the current surface, queue slot of the pending shadow ray, of the extension ray
 };
 struct WfState {
   WfPath* p;
@@ -84,7 +84,10 @@ struct WfQueues {
   uint32_t* active[2];    // path ids alive at the current / next depth
   uint32_t* shadow_ids;   // shadow-ray queue: path id ...
   float4* shadow_rays;    // ... and {o.xyz, t_max} {d.xyz, 0}
-  uint32_t* ext_ids;      // extension-ray queue (the ray is the path's ro / rd)
+  uint32_t* occluded;     // ... result of k_wf_trace<any hit>, by slot: 1 = something is in the way
+  uint32_t* ext_ids;      // extension-ray queue: path id ...
+  float4* ext_rays;       // ... {o.xyz, 0} {d.xyz, 0}
+  float4* ext_hit;        // ... result of k_wf_trace<closest hit>, by slot: {t, bits(triangle), bits(instance), 0}; instance < 0 = miss
   uint32_t* counters;     // 8 u32 per depth: n_active, n_shadow, n_ext, head_shadow, head_ext, 0, 0, 0
 };
 #define WF_FLAG_SPECULAR 0x100u

@@ -10,11 +10,13 @@ namespace rtk {
 // visits 70+ nodes with a long tail, and the per-trip lockstep of the persistent kernel leaves 60 % of the lanes idle
 // while they wait on L2 / Infinity-Cache latency.  The wavefront form splits a bounce into stages with the path state in
 // HBM (one 96-B record per path, 288 GB to spare):
-//   k_wf_shade   one lane per live path: surface frame + shade_bounce(); appends the shadow ray and the extension ray
-//                to device queues (wave-aggregated atomics), finishes paths that end
-//   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result and pulls the
-//                next ray from the queue (batched, >= RT_WF_REFILL lanes), so the slowest ray no longer holds 63 lanes;
-//                same node step / LDS triangle queue as traverse()
+//   k_wf_shade   one lane per live path: picks up the results of the previous depth's rays by queue slot (pending NEE
+//                term, hit of the extension ray), surface frame + shade_bounce(); appends the shadow ray and the
+//                extension ray WITH their ray data to device queues (wave-aggregated atomics), finishes paths that end
+//   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result to the ray's
+//                queue slot and pulls the next ray of the queue (batched, >= RT_WF_REFILL lanes), so the slowest ray
+//                no longer holds 63 lanes; same node step / LDS triangle queue as traverse().  Rays in, results out,
+//                both streamed by slot: the 96-byte path records are never touched here.
 // Stages of one depth run as separate launches in stream order; the host enqueues all depths without reading anything
 // back (queue sizes stay on the device).  Per path the arithmetic, RNG order and f32 addition order are unchanged, so
 // the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
@@ -54,14 +56,22 @@ __device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* id
 }
 
 __device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
-                                              rt3 nee) {
+                                              rt3 nee, uint32_t sslot, uint32_t eslot) {
   W.p[id].a = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
   W.p[id].b = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
   W.p[id].c = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
   W.p[id].d = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
   W.p[id].e = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
+  W.p[id].m = make_uint4(p.inst, sslot, eslot, 0u);
 }
 
+// One lane per path that is alive at `depth`.  FIRST: the paths start at the pixels of the batch (camera ray + G-buffer
+// surface).  Otherwise a path comes from the active list the previous depth's shade kernel wrote, and FIRST picks up what
+// the two trace kernels left for it BY QUEUE SLOT: the occlusion bit of its shadow ray (the pending NEE term is added
+// now, before anything else touches the radiance — the order of f32 additions of the reference) and the hit of its
+// extension ray (a miss ends the path).  A path that had ended but was waiting for its shadow ray is finished here; the
+// host launches one more pass after the last depth for those.  The trace kernels therefore never touch the path state:
+// they stream their queue in and their results out.
 template <bool FIRST, bool DETAIL>
 __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_scene_uniforms U, WfState W, WfQueues Q,
                                                   const DevFrameSlot* __restrict__ slots, uint32_t n_slots,
@@ -70,8 +80,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
   uint32_t* cnt = Q.counters + 8u * depth;
   const uint32_t count = FIRST ? npx * n_slots : cnt[0];
   const uint32_t* active_in = Q.active[depth & 1u];
+  uint32_t* next_active = Q.active[(depth + 1u) & 1u];
+  uint32_t* next_count = Q.counters + 8u * (depth + 1u);
   uint32_t cnt_shaded = 0;
-  WaveQueueWriter wq_shadow = {0u, 0u}, wq_ext = {0u, 0u};
+  WaveQueueWriter wq_shadow = {0u, 0u}, wq_ext = {0u, 0u}, wq_next = {0u, 0u};
   // wave-uniform loop (every lane of a wave takes part in the queue appends)
   for (uint32_t base_idx = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base_idx < count; base_idx += gridDim.x * 256u) {
     const uint32_t idx = base_idx + (threadIdx.x & 63u);
@@ -136,20 +148,37 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
         setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
       }
     } else {
-      const float4 a = W.p[id].a, b = W.p[id].b, c = W.p[id].c, d = W.p[id].d, e = W.p[id].e;
-      p.ro = xyz(a);
-      p.hit_t = a.w;
-      p.rd = xyz(b);
-      p.prev_pdf = b.w;
-      p.throughput = xyz(c);
-      p.rng = rt_f2u(c.w);
-      p.radiance = xyz(d);
+      const float4 d = W.p[id].d;
+      const uint4 m = W.p[id].m;
       const uint32_t fl = rt_f2u(d.w);
-      p.depth = fl & 0xffu;
-      p.specular = (fl & WF_FLAG_SPECULAR) != 0u;
-      p.tri = rt_f2u(e.w);
-      p.inst = W.p[id].inst;
-      setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+      p.radiance = xyz(d);
+      if (m.y != RT_WF_INVALID && (fl & WF_FLAG_NEE_VALID) != 0u && Q.occluded[m.y] == 0u) {
+        const float4 e = W.p[id].e;
+        p.radiance = p.radiance + xyz(e);  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
+      }
+      float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      bool over = (fl & WF_FLAG_ENDED) != 0u;
+      if (!over) {
+        h = Q.ext_hit[m.z];
+        over = (int32_t)rt_f2u(h.z) < 0;  // miss: the path ends with what it has
+      }
+      if (over) {
+        F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
+        live = false;
+      } else {
+        const float4 a = W.p[id].a, b = W.p[id].b, c = W.p[id].c;
+        p.ro = xyz(a);
+        p.rd = xyz(b);
+        p.prev_pdf = b.w;
+        p.throughput = xyz(c);
+        p.rng = rt_f2u(c.w);
+        p.depth = (fl & 0xffu) + 1u;
+        p.specular = (fl & WF_FLAG_SPECULAR) != 0u;
+        p.hit_t = h.x;
+        p.tri = rt_f2u(h.y);
+        p.inst = rt_f2u(h.z);
+        setup_surface(S, p, false, 0.0f, 0.0f, 0u);
+      }
     }
     if (live) {
       if (DETAIL) cnt_shaded++;
@@ -163,27 +192,37 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
       Q.shadow_rays[2 * sslot + 1] = make_float4(bo.sh_d.x, bo.sh_d.y, bo.sh_d.z, 0.0f);
     }
     const uint32_t eslot = wq_append(wq_ext, &cnt[2], Q.ext_ids, live && bo.want_extend);
-    if (eslot != RT_WF_INVALID) Q.ext_ids[eslot] = id;
+    if (eslot != RT_WF_INVALID) {
+      Q.ext_ids[eslot] = id;
+      Q.ext_rays[2 * eslot] = make_float4(p.ro.x, p.ro.y, p.ro.z, 0.0f);
+      Q.ext_rays[2 * eslot + 1] = make_float4(p.rd.x, p.rd.y, p.rd.z, 0.0f);
+    }
+    // the path goes on to the next depth's shade pass when something is pending for it
+    const uint32_t nslot = wq_append(wq_next, &next_count[0], next_active, live && (bo.want_shadow || bo.want_extend));
+    if (nslot != RT_WF_INVALID) next_active[nslot] = id;
     if (live) {
       if (bo.ended && !bo.want_shadow) {
         F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
       } else {
         const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
                                (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
-        wf_store_path(W, id, p, flags, bo.nee);
+        wf_store_path(W, id, p, flags, bo.nee, sslot, eslot);
       }
     }
   }
   wq_finish(wq_shadow, Q.shadow_ids);
   wq_finish(wq_ext, Q.ext_ids);
+  wq_finish(wq_next, next_active);
   if (DETAIL) {
     LaneCounters c = {0, 0, 0, 0, 0, cnt_shaded};
     flush_counters<true>(c, F.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
   }
 }
 
-// Persistent ray tracer over a device queue. ANY: shadow rays (result: NEE term added, ended paths finished);
-// else extension rays (result: hit stored + path appended to the next depth's active list, or path finished on a miss).
+// Persistent ray tracer over a device queue: rays stream in by queue slot ({o, t_max} {d} written by k_wf_shade) and
+// results stream out by queue slot — ANY (shadow rays): one occlusion word; else (extension rays): {t, triangle,
+// instance} of the closest hit.  The path state is not touched here.  Ray-level regeneration: a lane whose ray is
+// finished writes its result and, when >= RT_WF_REFILL lanes are idle, the wave pulls the next rays of its chunk.
 // BLOCK threads per workgroup (256 / 512 / 1024): a bigger workgroup shares one staged treelet among more waves, so
 // the LDS copy of the top of the tree can be larger (LdsPlan, rt_api.hip plan_lds) at the price of fewer waves per SIMD
 // than the 256-thread form allows.  LDS = true: every traversal record fits (RT_TRAV_LDS).
@@ -194,18 +233,30 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 // sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
 // triangle flush; [3..5] = how often each section did work; [6] = waves; [7] = loop trips.  Nothing else reads it.
 __device__ unsigned long long g_trace_sections[2][8];
+// Queue prefetch.  Pulling rays used to cost a wave ~16 000 cycles per refill (a returning atomic for the chunk, then the
+// id and the ray of every needy lane: dependent HBM round trips during which the lanes that still have a ray stand
+// still) — a quarter of the kernel.  Each wave now keeps the next RT_WF_PF entries of its chunk in LDS, fetched by LDS-DMA
+// (global_load_lds: no VGPRs, lane i's entry lands at slot i) as soon as the previous batch is used up, and the next
+// chunk is reserved while the last batch of the current one is in flight; a refill then reads LDS.
+#define RT_WF_PF 64u
+#define RT_WF_PF_BYTES (RT_WF_PF * 4u + 2u * RT_WF_PF * 16u)          // ids + {o, t_max} + {d}
+#define RT_WF_LDS_PER_WAVE (RT_WORK_BYTES_PER_WAVE + RT_WF_PF_BYTES)
+typedef __attribute__((address_space(3))) void* rt_lds_void;
+typedef const __attribute__((address_space(1))) void* rt_glb_void;
+
 template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
-void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
+void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
                 uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
   extern __shared__ f4 s_scene[];
   WaveWork W;
-  {
-    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
-    W.rays = reinterpret_cast<f4*>(wbase);
-    W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
-  }
-  const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
+  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WF_LDS_PER_WAVE;
+  W.rays = reinterpret_cast<f4*>(wbase);
+  W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  uint32_t* const pf_ids = reinterpret_cast<uint32_t*>(wbase + RT_WORK_BYTES_PER_WAVE);
+  f4* const pf_r0 = reinterpret_cast<f4*>(wbase + RT_WORK_BYTES_PER_WAVE + RT_WF_PF * 4u);
+  f4* const pf_r1 = pf_r0 + RT_WF_PF;
+  const uint32_t rec0 = ((BLOCK / 64) * RT_WF_LDS_PER_WAVE) / 16;
   TravMem M;
   if (LDS) {
     LdsPlan all;
@@ -223,18 +274,59 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
   uint32_t* cnt = Q.counters + 8u * depth;
   const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
   uint32_t* head = ANY ? &cnt[3] : &cnt[4];
-  uint32_t* next_active = Q.active[(depth + 1u) & 1u];
-  uint32_t* next_count = Q.counters + 8u * (depth + 1u);
+  const uint32_t* ids = ANY ? Q.shadow_ids : Q.ext_ids;
+  const float4* rays = ANY ? Q.shadow_rays : Q.ext_rays;
 
   // per-lane ray + traversal state
   bool have_ray = false;
-  uint32_t id = 0u;
+  uint32_t slot = 0u;
   Trav s;
   trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), RT_T_MIN, 0.0f);
+  // wave-uniform queue cursors: [chunk_pos, chunk_end) = what is left of the chunk this wave holds; next_chunk = the
+  // chunk reserved ahead (its index arrives while the current one is traced); pf_* = the batch prefetched into LDS
   bool queue_left = true;
-  uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
-  WaveQueueWriter wq_next = {0u, 0u};       // output: the next depth's active list (extension rays only)
+  uint32_t chunk_pos = 0u, chunk_end = 0u, next_chunk = 0u;
+  bool have_next = false;
+  uint32_t pf_base = 0u, pf_n = 0u, pf_pos = 0u;
   uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
+  // start the LDS-DMA of the next batch (nothing waits for it here)
+  auto prefetch_batch = [&]() {
+    if (chunk_pos >= chunk_end) {
+      uint32_t bq;
+      if (have_next) {
+        bq = next_chunk;
+        have_next = false;
+      } else {
+        bq = 0u;
+        if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+        bq = __shfl(bq, 0, 64);
+      }
+      if (bq >= n_rays) {
+        queue_left = false;
+        return;
+      }
+      chunk_pos = bq;
+      chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
+    }
+    const uint32_t n = chunk_end - chunk_pos < RT_WF_PF ? chunk_end - chunk_pos : RT_WF_PF;
+    if (lane < n) {
+      const uint32_t qi = chunk_pos + lane;
+      __builtin_amdgcn_global_load_lds((rt_glb_void)(ids + qi), (rt_lds_void)pf_ids, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((rt_glb_void)(rays + 2 * (size_t)qi), (rt_lds_void)pf_r0, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((rt_glb_void)(rays + 2 * (size_t)qi + 1), (rt_lds_void)pf_r1, 16, 0, 0);
+    }
+    pf_base = chunk_pos;
+    pf_n = n;
+    pf_pos = 0u;
+    chunk_pos += n;
+    if (chunk_pos >= chunk_end && !have_next) {  // the last batch of the chunk is on its way: reserve the next chunk now
+      uint32_t bq = 0u;
+      if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+      next_chunk = __shfl(bq, 0, 64);
+      have_next = true;
+    }
+  };
+  prefetch_batch();
 
 #ifdef RT_TRACE_STAMPS
   unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
@@ -251,95 +343,40 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
     const unsigned long long busy_m = __ballot(s.searching || s.waiting);
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
-         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+         ((queue_left || pf_pos < pf_n) && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
 #ifdef RT_TRACE_STAMPS
       st_cnt[0]++;
 #endif
-      bool push_next = false;
       if (done) {
-        if (ANY) {
-          float4 dd = Ws.p[id].d;
-          const uint32_t fl = rt_f2u(dd.w);
-          if (!s.any && (fl & WF_FLAG_NEE_VALID) != 0u) {
-            const float4 e = Ws.p[id].e;
-            dd.x = dd.x + e.x;  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
-            dd.y = dd.y + e.y;
-            dd.z = dd.z + e.z;
-          }
-          if ((fl & WF_FLAG_ENDED) != 0u)
-            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
-          else
-            Ws.p[id].d = dd;
-        } else {
-          if (s.best_inst < 0) {  // miss: the path ends with what it has
-            const float4 dd = Ws.p[id].d;
-            F.frame_col[id] = make_float4(dd.x, dd.y, dd.z, 1.0f);
-          } else {
-            float4 a = Ws.p[id].a;
-            a.w = s.closest;
-            Ws.p[id].a = a;
-            float4 e = Ws.p[id].e;
-            e.w = rt_u2f((uint32_t)s.best_tri);
-            Ws.p[id].e = e;
-            Ws.p[id].inst = (uint32_t)s.best_inst;
-            float4 dd = Ws.p[id].d;
-            const uint32_t fl = rt_f2u(dd.w);
-            dd.w = rt_u2f((fl & ~0xffu) | (((fl & 0xffu) + 1u) & 0xffu));  // depth++
-            Ws.p[id].d = dd;
-            push_next = true;
-          }
-        }
+        if (ANY)
+          Q.occluded[slot] = s.any ? 1u : 0u;
+        else
+          Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
         have_ray = false;
       }
-      if (!ANY) {
-        const uint32_t slot = wq_append(wq_next, &next_count[0], next_active, push_next);
-        if (slot != RT_WF_INVALID) next_active[slot] = id;
-      }
-      // pull: needy lanes take consecutive entries of the wave's chunk; a new chunk costs one atomic
+      // pull: needy lanes take consecutive entries of the prefetched batch (LDS); when the batch is used up the next
+      // one is requested and arrives while the wave goes on tracing
       const bool need = !have_ray;
       const unsigned long long need_m = __ballot(need);
-      if (queue_left && need_m != 0ull) {
-        if (chunk_pos >= chunk_end) {
-          uint32_t bq = 0;
-          if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
-          bq = __shfl(bq, 0, 64);
-          if (bq >= n_rays) {
-            queue_left = false;
-          } else {
-            chunk_pos = bq;
-            chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
-          }
+      if (need_m != 0ull && pf_pos < pf_n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this batch has landed
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+        const uint32_t e = pf_pos + rank;
+        if (need && e < pf_n && pf_ids[e] != RT_WF_INVALID) {
+          const f4 r0 = pf_r0[e], r1 = pf_r1[e];
+          slot = pf_base + e;
+          n_traced++;
+          have_ray = true;
+          trav_begin(s, true, blas_base, rt3_make(r0.x, r0.y, r0.z), rt3_make(r1.x, r1.y, r1.z), RT_T_MIN, ANY ? r0.w : RT_T_MAX);
         }
-        if (queue_left) {
-          const uint32_t rank =
-              __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
-          const uint32_t qi = chunk_pos + rank;
-          chunk_pos += (uint32_t)__builtin_popcountll(need_m);
-          if (need && qi < chunk_end) {
-            const uint32_t rid = ANY ? Q.shadow_ids[qi] : Q.ext_ids[qi];
-            if (rid != RT_WF_INVALID) {
-              id = rid;
-              rt3 o, d;
-              float t_max;
-              if (ANY) {
-                const float4 r0 = Q.shadow_rays[2 * qi], r1 = Q.shadow_rays[2 * qi + 1];
-                o = xyz(r0);
-                d = xyz(r1);
-                t_max = r0.w;
-              } else {
-                o = xyz(Ws.p[id].a);
-                d = xyz(Ws.p[id].b);
-                t_max = RT_T_MAX;
-              }
-              n_traced++;
-              have_ray = true;
-              trav_begin(s, true, blas_base, o, d, RT_T_MIN, t_max);
-            }
-          }
-        }
+        const uint32_t taken = (uint32_t)__builtin_popcountll(need_m);
+        pf_pos = pf_pos + taken < pf_n ? pf_pos + taken : pf_n;
+        __builtin_amdgcn_wave_barrier();                   // every lane has read its entry before the batch is replaced
       }
+      if (pf_pos >= pf_n && queue_left) prefetch_batch();
     }
-    if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+    if (!queue_left && pf_pos >= pf_n && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
 
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -371,7 +408,6 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfState Ws, WfQueu
     atomicAdd(&g_trace_sections[ANY ? 1 : 0][7], st_trips);
   }
 #endif
-  if (!ANY) wq_finish(wq_next, next_active);
   LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
   flush_counters<DETAIL>(c, F.counters, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
 }

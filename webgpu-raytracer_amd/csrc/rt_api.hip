@@ -913,34 +913,38 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   if (r < 0) return r;
   // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
   const size_t qcap = items + (size_t)5 * 1024 * 1024;
-  r = ensure_buffer(c, c->wf_queues, qcap * 48, false);  // active[2] + shadow ids + ext ids (4 x 4 B) + shadow rays (32 B)
+  // per item: active[2] + shadow ids + ext ids + occlusion word (5 x 4 B) + shadow rays, extension rays (2 x 32 B) + hits (16 B)
+  r = ensure_buffer(c, c->wf_queues, qcap * 100, false);
   if (r < 0) return r;
   const uint32_t depths = c->max_depth ? c->max_depth : 1u;
-  r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 1) * 32, false);
+  r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 2) * 32, false);
   if (r < 0) return r;
-  HIP_TRY(c, hipMemsetAsync(c->wf_counters.ptr, 0, (size_t)(depths + 1) * 32, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->wf_counters.ptr, 0, (size_t)(depths + 2) * 32, c->stream));
   WfState W;
   W.p = (WfPath*)c->wf_state.ptr;
   WfQueues Q;
   char* qb = (char*)c->wf_queues.ptr;
   Q.shadow_rays = (float4*)qb;
-  Q.active[0] = (uint32_t*)(qb + qcap * 32);
-  Q.active[1] = (uint32_t*)(qb + qcap * 36);
-  Q.shadow_ids = (uint32_t*)(qb + qcap * 40);
-  Q.ext_ids = (uint32_t*)(qb + qcap * 44);
+  Q.ext_rays = (float4*)(qb + qcap * 32);
+  Q.ext_hit = (float4*)(qb + qcap * 64);
+  Q.active[0] = (uint32_t*)(qb + qcap * 80);
+  Q.active[1] = (uint32_t*)(qb + qcap * 84);
+  Q.shadow_ids = (uint32_t*)(qb + qcap * 88);
+  Q.ext_ids = (uint32_t*)(qb + qcap * 92);
+  Q.occluded = (uint32_t*)(qb + qcap * 96);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
   const bool detail = c->detailed_counters;
   // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
   // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
   // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
   const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
-  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WF_LDS_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
   if (!trace_lds) {
     block = c->wf_block ? c->wf_block : 256;
     blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : (block == 1024 ? 1 : (block == 512 ? 2 : 6));
   }
-  const size_t queue_bytes = (size_t)(block / 64) * RT_WORK_BYTES_PER_WAVE;
+  const size_t queue_bytes = (size_t)(block / 64) * RT_WF_LDS_PER_WAVE;   // triangle queue + prefetched rays per wave
   size_t dyn = queue_bytes + lds_records;
   rtk::LdsPlan plan;
   plan.k_nodes = c->n_nodes;
@@ -988,12 +992,24 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       DevScene Sa = S;
       DevFrame Fa = F;
       rt_scene_uniforms Ua = c->uniforms;
-      void* args[] = {&Sa, &Fa, &Ua, &W, &Q, &depth, &nn, &nt, &ni, &plan};
+      void* args[] = {&Sa, &Fa, &Ua, &Q, &depth, &nn, &nt, &ni, &plan};
       EventPair* evt = next_events(c, k == 0 ? RT_TIMER_WF_TRACE_SHADOW : RT_TIMER_WF_TRACE_EXT);
       if (evt) HIP_TRY(c, hipEventRecord(evt->a, c->stream));
       HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(block), args, dyn, c->stream));
       if (evt) HIP_TRY(c, hipEventRecord(evt->b, c->stream));
     }
+  }
+  {
+    // one more shade pass: the paths that ended at the last depth but were waiting for their shadow ray are finished
+    // here (every path of this list carries the ENDED flag, so nothing is shaded or queued)
+    EventPair* evs = next_events(c, RT_TIMER_WF_SHADE);
+    if (evs) HIP_TRY(c, hipEventRecord(evs->a, c->stream));
+    const uint32_t depth = depths;
+    if (detail)
+      hipLaunchKernelGGL((rtk::k_wf_shade<false, true>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+    else
+      hipLaunchKernelGGL((rtk::k_wf_shade<false, false>), dim3(shade_blocks), dim3(256), 0, c->stream, S, F, c->uniforms, W, Q, dslots, n, depth);
+    if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
   }
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
   hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots, n,
