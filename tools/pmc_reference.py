@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""profiles/pmc_reference.json from the per-kernel PMC averages of tools/make_profiles_r02.sh (profiles/r02_*_pmc.json),
+the in-kernel clock check and the VALU peak microbenchmark.  bench.py reads it for the fields it cannot measure from
+inside its own process; every such field is reported with this file's "source".
+usage: pmc_reference.py <dir with r02_*_pmc.json etc.> <commit> [out.json]"""
+import json
+import os
+import re
+import sys
+
+d, commit = sys.argv[1], sys.argv[2]
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_reference.json")
+
+
+def load(name):
+    p = os.path.join(d, name)
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def kernel(tab, prefix):
+    for k, v in tab.items():
+        if k.replace("rtk::", "").startswith(prefix):
+            return v
+    return {}
+
+
+ref = {"source": "rocprofv3 --pmc passes of tools/make_profiles_r02.sh (one counter set per run), collected at commit %s; "
+                 "per-kernel averages in profiles/r02_*_pmc.json" % commit,
+       "notes": {"FETCH_SIZE": "KB; doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B) - calibrated for wide "
+                               "coalesced reads only, so both the raw and the doubled figure are given",
+                 "WRITE_SIZE": "KB, exact for 16-B-per-lane stores",
+                 "lane_instr": "SQ_THREAD_CYCLES_VALU = active lanes summed over the VALU instructions of the launch"}}
+c = load("r02_cornell_pmc.json")
+pt = kernel(c, "k_pathtrace_persistent")
+if pt:
+    lane = pt.get("SQ_THREAD_CYCLES_VALU")
+    entry = {"frames_per_launch": 32, "dispatches_averaged": pt.get("dispatches"),
+             "insts_valu_per_launch": pt.get("SQ_INSTS_VALU"), "insts_salu_per_launch": pt.get("SQ_INSTS_SALU"),
+             "insts_lds_per_launch": pt.get("SQ_INSTS_LDS"), "lane_instr_per_launch": lane}
+    if pt.get("SQ_ACTIVE_INST_VALU"):
+        entry["valu_lane_utilization"] = round(lane / (pt["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+    if pt.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+            if pt.get(k):
+                entry["frac_of_wave_cycles_" + k[3:].lower()] = round(pt[k] / pt["SQ_WAVE_CYCLES"], 4)
+    if pt.get("SQ_LDS_BANK_CONFLICT") and pt.get("SQ_ACTIVE_INST_LDS"):
+        entry["lds_bank_conflict_frac_of_lds_cycles"] = round(pt["SQ_LDS_BANK_CONFLICT"] / pt["SQ_ACTIVE_INST_LDS"], 4)
+    if pt.get("FETCH_SIZE") is not None and pt.get("WRITE_SIZE") is not None:
+        entry["fetch_bytes_raw"] = pt["FETCH_SIZE"] * 1024.0
+        entry["fetch_bytes_doubled"] = pt["FETCH_SIZE"] * 2048.0
+        entry["write_bytes"] = pt["WRITE_SIZE"] * 1024.0
+        entry["hbm_bytes_per_launch"] = pt["FETCH_SIZE"] * 2048.0 + pt["WRITE_SIZE"] * 1024.0
+    clk = load("r02_clock_check.json")
+    if clk:
+        entry["effective_clock_GHz"] = clk.get("in_kernel_clock_GHz_median")
+        entry["cycles_per_workgroup"] = clk.get("cycles_per_workgroup_median")
+    vp = os.path.join(d, "r02_valu_peak.txt")
+    if os.path.exists(vp):
+        best = max(float(m) for m in re.findall(r"([0-9.]+) T lane-instr/s", open(vp).read()))
+        entry["measured_issue_peak_Tlane"] = best
+    ref["k_pathtrace_persistent"] = entry
+tr = {}
+for scene in ("sponza_like", "instanced1000", "glass_blob"):
+    t = load("r02_%s_pmc.json" % scene)
+    rows = {k: v for k, v in t.items() if "k_wf_trace" in k}
+    if not rows:
+        continue
+    e = {"frames_per_image_profiled": 32, "kernels": {}}
+    hbm = 0.0
+    for k, v in rows.items():
+        name = "any_hit" if "k_wf_trace<true" in k else "closest_hit"
+        n = v.get("dispatches", 0)
+        ke = {"dispatches": n}
+        if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None:
+            ke["hbm_bytes_per_dispatch"] = v["FETCH_SIZE"] * 2048.0 + v["WRITE_SIZE"] * 1024.0
+            hbm += ke["hbm_bytes_per_dispatch"] * n
+        if v.get("TCC_HIT_sum") is not None:
+            ke["l2_hit_rate"] = round(v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
+        if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            ke["l1_accesses_per_dispatch"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            ke["l1_miss_rate"] = round(v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+        if v.get("TCP_TCC_READ_REQ_sum") and v.get("TCP_TCC_READ_REQ_LATENCY_sum"):
+            ke["l2_read_latency_cycles"] = round(v["TCP_TCC_READ_REQ_LATENCY_sum"] / v["TCP_TCC_READ_REQ_sum"], 1)
+        if v.get("GRBM_GUI_ACTIVE") and v.get("TCP_PENDING_STALL_CYCLES_sum"):
+            cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+            ke["l1_pending_stall_frac"] = round(v["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc, 4)
+            ke["ta_busy_frac"] = round(v.get("TA_BUSY_avr", 0.0) / cyc, 4)
+        if v.get("SQ_WAVE_CYCLES"):
+            ke["wave_cycles_waiting_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+            if v.get("SQ_ACTIVE_INST_VALU"):
+                ke["valu_lane_utilization"] = round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+        e["kernels"][name] = ke
+    if hbm:
+        e["hbm_bytes_per_image"] = hbm * 2.0   # profiled on 32 of the image's 64 frames
+    tr[scene] = e
+if tr:
+    ref["k_wf_trace"] = tr
+json.dump(ref, open(out_path, "w"), indent=1)
+print(json.dumps(ref, indent=1)[:3000])

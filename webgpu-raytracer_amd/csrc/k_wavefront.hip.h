@@ -233,30 +233,16 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 // sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
 // triangle flush; [3..5] = how often each section did work; [6] = waves; [7] = loop trips.  Nothing else reads it.
 __device__ unsigned long long g_trace_sections[2][8];
-// Queue prefetch.  Pulling rays used to cost a wave ~16 000 cycles per refill (a returning atomic for the chunk, then the
-// id and the ray of every needy lane: dependent HBM round trips during which the lanes that still have a ray stand
-// still) — a quarter of the kernel.  Each wave now keeps the next RT_WF_PF entries of its chunk in LDS, fetched by LDS-DMA
-// (global_load_lds: no VGPRs, lane i's entry lands at slot i) as soon as the previous batch is used up, and the next
-// chunk is reserved while the last batch of the current one is in flight; a refill then reads LDS.
-#define RT_WF_PF 64u
-#define RT_WF_PF_BYTES (RT_WF_PF * 4u + 2u * RT_WF_PF * 16u)          // ids + {o, t_max} + {d}
-#define RT_WF_LDS_PER_WAVE (RT_WORK_BYTES_PER_WAVE + RT_WF_PF_BYTES)
-typedef __attribute__((address_space(3))) void* rt_lds_void;
-typedef const __attribute__((address_space(1))) void* rt_glb_void;
-
 template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
 void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
                 uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
   extern __shared__ f4 s_scene[];
   WaveWork W;
-  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WF_LDS_PER_WAVE;
+  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
   W.rays = reinterpret_cast<f4*>(wbase);
   W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
-  uint32_t* const pf_ids = reinterpret_cast<uint32_t*>(wbase + RT_WORK_BYTES_PER_WAVE);
-  f4* const pf_r0 = reinterpret_cast<f4*>(wbase + RT_WORK_BYTES_PER_WAVE + RT_WF_PF * 4u);
-  f4* const pf_r1 = pf_r0 + RT_WF_PF;
-  const uint32_t rec0 = ((BLOCK / 64) * RT_WF_LDS_PER_WAVE) / 16;
+  const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
   TravMem M;
   if (LDS) {
     LdsPlan all;
@@ -282,51 +268,9 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   uint32_t slot = 0u;
   Trav s;
   trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), RT_T_MIN, 0.0f);
-  // wave-uniform queue cursors: [chunk_pos, chunk_end) = what is left of the chunk this wave holds; next_chunk = the
-  // chunk reserved ahead (its index arrives while the current one is traced); pf_* = the batch prefetched into LDS
   bool queue_left = true;
-  uint32_t chunk_pos = 0u, chunk_end = 0u, next_chunk = 0u;
-  bool have_next = false;
-  uint32_t pf_base = 0u, pf_n = 0u, pf_pos = 0u;
+  uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
   uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
-  // start the LDS-DMA of the next batch (nothing waits for it here)
-  auto prefetch_batch = [&]() {
-    if (chunk_pos >= chunk_end) {
-      uint32_t bq;
-      if (have_next) {
-        bq = next_chunk;
-        have_next = false;
-      } else {
-        bq = 0u;
-        if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
-        bq = __shfl(bq, 0, 64);
-      }
-      if (bq >= n_rays) {
-        queue_left = false;
-        return;
-      }
-      chunk_pos = bq;
-      chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
-    }
-    const uint32_t n = chunk_end - chunk_pos < RT_WF_PF ? chunk_end - chunk_pos : RT_WF_PF;
-    if (lane < n) {
-      const uint32_t qi = chunk_pos + lane;
-      __builtin_amdgcn_global_load_lds((rt_glb_void)(ids + qi), (rt_lds_void)pf_ids, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((rt_glb_void)(rays + 2 * (size_t)qi), (rt_lds_void)pf_r0, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((rt_glb_void)(rays + 2 * (size_t)qi + 1), (rt_lds_void)pf_r1, 16, 0, 0);
-    }
-    pf_base = chunk_pos;
-    pf_n = n;
-    pf_pos = 0u;
-    chunk_pos += n;
-    if (chunk_pos >= chunk_end && !have_next) {  // the last batch of the chunk is on its way: reserve the next chunk now
-      uint32_t bq = 0u;
-      if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
-      next_chunk = __shfl(bq, 0, 64);
-      have_next = true;
-    }
-  };
-  prefetch_batch();
 
 #ifdef RT_TRACE_STAMPS
   unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
@@ -343,7 +287,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     const unsigned long long busy_m = __ballot(s.searching || s.waiting);
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
-         ((queue_left || pf_pos < pf_n) && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
 #ifdef RT_TRACE_STAMPS
       st_cnt[0]++;
 #endif
@@ -354,29 +298,37 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
           Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
         have_ray = false;
       }
-      // pull: needy lanes take consecutive entries of the prefetched batch (LDS); when the batch is used up the next
-      // one is requested and arrives while the wave goes on tracing
+      // pull: needy lanes take consecutive entries of the wave's chunk; a new chunk costs one atomic
       const bool need = !have_ray;
       const unsigned long long need_m = __ballot(need);
-      if (need_m != 0ull && pf_pos < pf_n) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this batch has landed
-        const uint32_t rank =
-            __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
-        const uint32_t e = pf_pos + rank;
-        if (need && e < pf_n && pf_ids[e] != RT_WF_INVALID) {
-          const f4 r0 = pf_r0[e], r1 = pf_r1[e];
-          slot = pf_base + e;
-          n_traced++;
-          have_ray = true;
-          trav_begin(s, true, blas_base, rt3_make(r0.x, r0.y, r0.z), rt3_make(r1.x, r1.y, r1.z), RT_T_MIN, ANY ? r0.w : RT_T_MAX);
+      if (queue_left && need_m != 0ull) {
+        if (chunk_pos >= chunk_end) {
+          uint32_t bq = 0;
+          if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+          bq = __shfl(bq, 0, 64);
+          if (bq >= n_rays) {
+            queue_left = false;
+          } else {
+            chunk_pos = bq;
+            chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
+          }
         }
-        const uint32_t taken = (uint32_t)__builtin_popcountll(need_m);
-        pf_pos = pf_pos + taken < pf_n ? pf_pos + taken : pf_n;
-        __builtin_amdgcn_wave_barrier();                   // every lane has read its entry before the batch is replaced
+        if (queue_left) {
+          const uint32_t rank =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+          const uint32_t qi = chunk_pos + rank;
+          chunk_pos += (uint32_t)__builtin_popcountll(need_m);
+          if (need && qi < chunk_end && ids[qi] != RT_WF_INVALID) {
+            const float4 r0 = rays[2 * qi], r1 = rays[2 * qi + 1];
+            slot = qi;
+            n_traced++;
+            have_ray = true;
+            trav_begin(s, true, blas_base, xyz(r0), xyz(r1), RT_T_MIN, ANY ? r0.w : RT_T_MAX);
+          }
+        }
       }
-      if (pf_pos >= pf_n && queue_left) prefetch_batch();
     }
-    if (!queue_left && pf_pos >= pf_n && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+    if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
 
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

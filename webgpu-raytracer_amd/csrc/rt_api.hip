@@ -938,13 +938,13 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
   // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
   const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
-  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WF_LDS_PER_WAVE <= 64 * 1024;
+  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
   if (!trace_lds) {
     block = c->wf_block ? c->wf_block : 256;
     blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : (block == 1024 ? 1 : (block == 512 ? 2 : 6));
   }
-  const size_t queue_bytes = (size_t)(block / 64) * RT_WF_LDS_PER_WAVE;   // triangle queue + prefetched rays per wave
+  const size_t queue_bytes = (size_t)(block / 64) * RT_WORK_BYTES_PER_WAVE;
   size_t dyn = queue_bytes + lds_records;
   rtk::LdsPlan plan;
   plan.k_nodes = c->n_nodes;
