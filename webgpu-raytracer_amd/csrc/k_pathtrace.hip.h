@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t a_, b_;
       bool occluded;
-      traverse<true, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, RT_T_MIN, sh_tmax, t_, a_, b_,
+      traverse<true, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_shadow, sh_o, sh_d, sh_tmax, t_, a_, b_,
                                    occluded, cnt_nodes, cnt_tris);
       if (want_shadow) {
         cnt_shadow++;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       float t_;
       int32_t tri_, inst_;
       bool any_;
-      traverse<false, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MIN, RT_T_MAX, t_, tri_,
+      traverse<false, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MAX, t_, tri_,
                                     inst_, any_, cnt_nodes, cnt_tris);
       if (want_extend) {
         cnt_ext++;

@@ -138,18 +138,16 @@ struct WaveWork {
 
 struct Trav {  // one ray's traversal state
   LocalRay r;                // the ray in the space it is currently walking (world or instance)
-  rt3 o, d;                  // world-space ray
-  float t_min, closest;
+  LocalRay rw;               // the world-space ray (rw.o, rw.d = the ray as given)
+  float closest;             // t_min is the constant RT_T_MIN for every ray of the reference (Raytracer.wgsl:6,688,732)
   int32_t best_tri, best_inst;
   uint32_t curr, tlas_next, cur_inst, leaf;
   bool searching, waiting, in_blas, any;
 };
 
-__device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_min, float t_max) {
-  s.o = o;
-  s.d = d;
-  s.r = make_ray(o, d);
-  s.t_min = t_min;
+__device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_max) {
+  s.rw = make_ray(o, d);
+  s.r = s.rw;
   s.closest = t_max;
   s.best_tri = -1;
   s.best_inst = -1;
@@ -166,21 +164,27 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
 // one node step for every searching lane; select-based, two branches only
 template <bool COUNT, int MODE>
 __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
-  // ---- the walk ran off its array (rare): leave the instance, or finish
-  if (s.searching && s.curr == RT_NODE_END) {
-    if (s.in_blas && s.tlas_next != RT_NODE_END) {
-      s.in_blas = false;  // back to the world-space ray and the TLAS cursor
-      s.r = make_ray(s.o, s.d);
-      s.curr = s.tlas_next;
-    } else {
-      s.searching = false;
-    }
+  // ---- the walk ran off its array (rare): leave the instance (back to the world-space ray and the TLAS cursor), or
+  // finish.  Written as selects behind a wave-uniform test: as a per-lane branch that recomputes the ray, the twelve
+  // registers of the ray were copied out and back on EVERY trip to merge the two paths.
+  const bool at_end = s.searching && s.curr == RT_NODE_END;
+  if (__ballot(at_end) != 0ull) {
+    const bool leave = at_end && s.in_blas && s.tlas_next != RT_NODE_END;
+    s.r.o.x = leave ? s.rw.o.x : s.r.o.x; s.r.o.y = leave ? s.rw.o.y : s.r.o.y; s.r.o.z = leave ? s.rw.o.z : s.r.o.z;
+    s.r.d.x = leave ? s.rw.d.x : s.r.d.x; s.r.d.y = leave ? s.rw.d.y : s.r.d.y; s.r.d.z = leave ? s.rw.d.z : s.r.d.z;
+    s.r.inv_d.x = leave ? s.rw.inv_d.x : s.r.inv_d.x; s.r.inv_d.y = leave ? s.rw.inv_d.y : s.r.inv_d.y;
+    s.r.inv_d.z = leave ? s.rw.inv_d.z : s.r.inv_d.z;
+    s.r.o_inv_d.x = leave ? s.rw.o_inv_d.x : s.r.o_inv_d.x; s.r.o_inv_d.y = leave ? s.rw.o_inv_d.y : s.r.o_inv_d.y;
+    s.r.o_inv_d.z = leave ? s.rw.o_inv_d.z : s.r.o_inv_d.z;
+    s.curr = leave ? s.tlas_next : s.curr;
+    s.in_blas = s.in_blas && !leave;
+    s.searching = s.searching && (!at_end || leave);
   }
   if (s.searching) {
     f4 lo, hi;
     trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
     if (COUNT) n_nodes++;
-    const bool hit = hit_box4(lo, hi, s.r, s.t_min, s.closest);
+    const bool hit = hit_box4(lo, hi, s.r, RT_T_MIN, s.closest);
     const uint32_t data = rt_f2u(hi.w);
     const bool inner = (data & RT_NODE_INNER) != 0u;
     const bool leafhit = hit && !inner;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav&
     if (leafhit && !s.in_blas) {  // TLAS leaf: enter the instance
       s.cur_inst = data >> 3;
       uint32_t root;
-      s.r = to_instance<MODE>(M, lds, s.cur_inst, s.o, s.d, root);
+      s.r = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
       s.tlas_next = next;
       next = root;
       s.in_blas = true;
@@ -222,7 +226,7 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
   const uint32_t first = s.leaf >> 3;
   if (s.waiting) {
     f4 ra, rb;
-    ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = s.t_min;
+    ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = RT_T_MIN;
     rb.x = rt_opaque(s.r.d.x); rb.y = rt_opaque(s.r.d.y); rb.z = rt_opaque(s.r.d.z); rb.w = s.closest;
     W.rays[2 * lane] = ra;
     W.rays[2 * lane + 1] = rb;
@@ -288,10 +292,10 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
 // traverse(): the whole walk of one wave's rays (persistent kernel, one traversal per bounce and ray kind)
 template <bool ANY, bool COUNT, int MODE>
 __device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const WaveWork& W, uint32_t blas_base, bool active,
-                                         rt3 o, rt3 d, float t_min, float t_max, float& out_t, int32_t& out_tri,
+                                         rt3 o, rt3 d, float t_max, float& out_t, int32_t& out_tri,
                                          int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
   Trav s;
-  trav_begin(s, active, blas_base, o, d, t_min, t_max);
+  trav_begin(s, active, blas_base, o, d, t_max);
   for (;;) {
     trav_step<COUNT, MODE>(M, lds, s, n_nodes);
     if (!trav_flush<ANY, COUNT, MODE>(M, lds, W, s, n_tris)) break;

@@ -267,7 +267,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   bool have_ray = false;
   uint32_t slot = 0u;
   Trav s;
-  trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), RT_T_MIN, 0.0f);
+  trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), 0.0f);
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
   uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
@@ -323,7 +323,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
             slot = qi;
             n_traced++;
             have_ray = true;
-            trav_begin(s, true, blas_base, xyz(r0), xyz(r1), RT_T_MIN, ANY ? r0.w : RT_T_MAX);
+            trav_begin(s, true, blas_base, xyz(r0), xyz(r1), ANY ? r0.w : RT_T_MAX);
           }
         }
       }
