@@ -42,4 +42,13 @@ if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
     python3 $R/tools/pmc_collect.py $OUT/pmc_$scene $OUT/r02_${scene}_pmc.json > /dev/null
   done
 fi
+if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
+  # config 5 (4K, depth 16): kernel trace of one 8-frame batch
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_glass -- python3 $R/tools/prof_workload.py glass_blob 8 16 8 1 3840 2160 > $OUT/trace_glass_blob.log 2>&1
+  cp $OUT/trace_glass/*/*_kernel_stats.csv $OUT/r02_glass_blob_kernel_stats.csv
+  rm -rf $OUT/trace_glass
+fi
+timeout -k 10 120 $R/tools/bin/valu_peak > $OUT/r02_valu_peak.txt 2>&1
+timeout -k 10 200 python3 $R/tools/clock_check.py $OUT/r02_clock_check.json > $OUT/clock_check.log 2>&1
+python3 $R/tools/pmc_reference.py $OUT ${HEAD:-unknown} $OUT/pmc_reference.json > /dev/null
 ls $OUT
