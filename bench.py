@@ -278,9 +278,13 @@ def main():
             roof["achieved"] = round(lane / (launch_ms * 1e-3) / 1e12, 3)
             roof["frac"] = round(roof["achieved"] / VALU_PEAK_TLANE, 4)
             roof["lane_instr_per_launch"] = {"value": lane, "source": src}
-            for k in ("valu_lane_utilization", "valu_busy_frac", "effective_clock_GHz", "measured_issue_peak_Tlane"):
+            for k in ("valu_lane_utilization", "effective_clock_GHz", "measured_issue_peak_Tlane", "insts_valu_per_launch",
+                      "insts_salu_per_launch", "frac_of_wave_cycles_active_inst_any", "frac_of_wave_cycles_wait_any",
+                      "frac_of_wave_cycles_wait_inst_any", "lds_bank_conflict_frac_of_lds_cycles"):
                 if k in pt:
                     roof[k] = {"value": pt[k], "source": src}
+            if pt.get("measured_issue_peak_Tlane"):
+                roof["frac_of_measured_issue_peak"] = round(roof["achieved"] / pt["measured_issue_peak_Tlane"], 4)
             if pt.get("hbm_bytes_per_launch"):
                 tb = pt["hbm_bytes_per_launch"] * scale
                 roof["traffic"] = tb
@@ -320,15 +324,21 @@ def main():
             if per_image_trace_ms > 0:
                 gbps = trace_bytes / (per_image_trace_ms * 1e-3) / 1e9
                 rk = ref.get("k_wf_trace", {}).get(scene, {}) if world == 1 else {}
-                entry["roofline"] = {"kernel": "k_wf_trace (any-hit + closest-hit launches)", "bound": "hbm",
-                                     "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(gbps / HBM_PEAK_GBS, 4), "l2_peak": L2_PEAK_GBS,
-                                     "l2_frac": round(gbps / L2_PEAK_GBS, 4),
-                                     "alg_bytes_per_image": int(trace_bytes),
-                                     "served_by": "L1 / L2 / Infinity Cache (the scene, <= 40 MB, stays on die); "
-                                                  "algorithmic bytes = 32 B per node visit + 64 B per triangle test",
-                                     "traffic": rk.get("hbm_bytes_per_image"),
-                                     "traffic_source": ref.get("source") if rk else None}
+                roof_c = {"kernel": "k_wf_trace (any-hit + closest-hit launches)", "bound": "hbm",
+                          "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gbps / HBM_PEAK_GBS, 4), "l2_peak": L2_PEAK_GBS,
+                          "l2_frac": round(gbps / L2_PEAK_GBS, 4),
+                          "alg_bytes_per_image": int(trace_bytes), "trace_ms_per_image": round(per_image_trace_ms, 3),
+                          "served_by": "LDS treelet / L1 / L2 / Infinity Cache: the scene (<= 40 MB) stays on die, so the "
+                                       "algorithmic bytes (32 B per node visit + 64 B per triangle test) are NOT HBM traffic; "
+                                       "`traffic` is the measured fabric-side figure",
+                          "traffic": rk.get("hbm_bytes_per_image"), "traffic_source": ref.get("source") if rk else None}
+                if rk.get("hbm_bytes_per_image"):
+                    roof_c["traffic_GBps"] = round(rk["hbm_bytes_per_image"] / (per_image_trace_ms * 1e-3) / 1e9, 1)
+                    roof_c["traffic_frac_of_hbm_peak"] = round(roof_c["traffic_GBps"] / HBM_PEAK_GBS, 4)
+                if rk.get("kernels"):
+                    roof_c["pmc"] = {"value": rk["kernels"], "source": ref.get("source")}
+                entry["roofline"] = roof_c
             cfgs.append(entry)
         if cfgs:
             out["configs"] = cfgs
