@@ -4,7 +4,8 @@
 // (rust-shader-tools/src/lib.rs:186-193 -> rebuilder.rs:93-98 -> bvh/blas.rs), 147 ms for 263 k triangles here — 26x the
 // time this renderer needs to trace a frame of that scene, so an animated scene is build-bound.  A different builder
 // (LBVH, refit) would change the traversal order and with it tie-breaks and the node / triangle counters, so this one
-// makes the SAME tree: 16 bins on the longest axis of the node's box, SAH sweep, two-pointer partition, costlier child
+// makes the SAME tree: 16 bins on the axis the reference picks (blas.rs:106: y if extent.y > extent.x, else z if it exceeds both, else x — NOT
+// the longest axis), SAH sweep, two-pointer partition, costlier child
 // first, leaves at <= 4 triangles (blas.rs:99-234 as restated in csrc/scene/scene_compiler.cpp BlasBuilder; the
 // parity test compares node arrays and triangle order byte for byte).
 //

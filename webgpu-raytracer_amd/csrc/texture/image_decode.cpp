@@ -9,7 +9,8 @@
 //             intervals;
 //             integer IDCT, triangle chroma upsampling and fixed-point YCbCr -> RGB follow the algorithms the IJG
 //             library documents (jidctint / jdsample "fancy" / jdcolor), so output equals the common decoders' bit for bit
-// No GPU, no third-party code; plain C ABI.
+// No GPU, no library dependency; plain C ABI.  Written from the specifications; the canonical-Huffman construction and
+// decode loop of the inflater have the shape of zlib's contrib puff.c (Mark Adler), the usual way to write them.
 #include "../../../include/mi355tex.h"
 
 #include <stdlib.h>
