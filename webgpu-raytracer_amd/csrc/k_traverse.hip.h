@@ -131,6 +131,9 @@ struct WaveWork {
   uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
 };
 #define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#ifndef RT_STEPS_PER_TRIP
+#define RT_STEPS_PER_TRIP 4  // swept on MI355X (Cornell, ms per 32-frame launch): 1: 27.1, 2: 26.0, 3: 25.8, 4: 25.1, 6: 25.0, 8: 25.8, 12: 27.4
+#endif
 #ifndef RT_FLUSH_ITEMS
 #define RT_FLUSH_ITEMS 24u  // queued triangle tests that trigger a flush; swept 1..128 on MI355X: flat optimum 16..32
                             // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
@@ -297,7 +300,10 @@ __device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const 
   Trav s;
   trav_begin(s, active, blas_base, o, d, t_max);
   for (;;) {
-    trav_step<COUNT, MODE>(M, lds, s, n_nodes);
+    // RT_STEPS_PER_TRIP node steps between two looks at the triangle queue: the look (ballots, population counts, the
+    // branch) costs a third of a trip; a lane that reaches a leaf in an earlier step simply sits out the later ones
+#pragma unroll
+    for (int k = 0; k < RT_STEPS_PER_TRIP; k++) trav_step<COUNT, MODE>(M, lds, s, n_nodes);
     if (!trav_flush<ANY, COUNT, MODE>(M, lds, W, s, n_tris)) break;
   }
   out_t = s.closest;

@@ -21,7 +21,9 @@ namespace rtk {
 // back (queue sizes stay on the device).  Per path the arithmetic, RNG order and f32 addition order are unchanged, so
 // the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
 // Restriction: SPP == 1 (the reference's default); other SPP values use the persistent kernel.
+#ifndef RT_WF_REFILL
 #define RT_WF_REFILL 16
+#endif
 
 // Device queues are filled and drained in chunks of RT_WF_CHUNK entries: a wave reserves a chunk with ONE atomic
 // and then appends with ballot/mbcnt ranks (a queue counter is a single address: ~88 atomics/us chip-wide, so one atomic
@@ -229,6 +231,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_sce
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 6
 #endif
+#ifndef RT_WF_STEPS_PER_TRIP
+#define RT_WF_STEPS_PER_TRIP 4   // node steps between two looks at the ray queue and the triangle queue; swept on sponza-like
+                                 // (ms per 32 frames): 1: 153.0, 2: 137.7, 3: 134.5, 4: 133.2, 6: 132.0, 8: 131.4
+#endif
 // Diagnostic build only (-DRT_TRACE_STAMPS, tools/trace_sections.py): per-wave s_memtime cycles spent in the three
 // sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
 // triangle flush; [3..5] = how often each section did work; [6] = waves; [7] = loop trips.  Nothing else reads it.
@@ -336,7 +342,8 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     st_cyc[0] += st1 - st0;
     if (__ballot(s.searching) != 0ull) st_cnt[1]++;
 #endif
-    trav_step<DETAIL, MODE>(M, s_scene, s, n_nodes);
+#pragma unroll
+    for (int k = 0; k < RT_WF_STEPS_PER_TRIP; k++) trav_step<DETAIL, MODE>(M, s_scene, s, n_nodes);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
