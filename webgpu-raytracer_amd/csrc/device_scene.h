@@ -11,6 +11,10 @@
 //   inst_root  u32 / inst          index in tnodes of the instance's BLAS root
 //   tri_geom   3 x float4 / tri    {v0, _} {e1 = v1-v0, _} {e2 = v2-v0, _}   (48 B instead of the
 //              80-B topology row + 3 dependent 16-B position gathers, Raytracer.wgsl:476-477)
+//   tri_shade  8 x float4 / tri    rows 1..4 of the topology record (material attributes), then the three vertex normals and
+//              uvs: {n0, uv0.x} {n1, uv0.y} {n2, uv1.x} {uv1.y, uv2.x, uv2.y, 0}.  One aligned 128-byte line per shaded hit
+//              instead of the 80-B topology row + six dependent 16-/8-byte vertex gathers through its index row (ten cache
+//              lines): the shade kernels of the large scenes are bound by exactly that line traffic
 //   inst_trav  4 x float4 / inst   rows 0..2 of the inverse matrix (so M*p is 3 dot-like rows),
 //              {blas_node_offset, inv[3], inv[7], inv[11]}                    (64 B instead of 144 B)
 //   light_rec  4 x float4 / light  world-space light triangle, its unit normal and area (what sample_light_source
@@ -30,6 +34,7 @@ struct DevScene {
   const float4* tnodes;     // 2 per node: the same nodes with explicit successors, treelet first (k_treelet.hip.h)
   const uint32_t* inst_root;  // 1 per instance: index in tnodes of the instance's BLAS root
   const float4* tri_geom;   // 3 per triangle
+  const float4* tri_shade;  // 8 per triangle: what shading reads about a hit, in ONE 128-byte line
   const float4* inst_trav;  // 4 per instance
   const float4* topo;       // 5 per triangle (raw MeshTopology rows)
   const float4* pos;        // 1 per vertex

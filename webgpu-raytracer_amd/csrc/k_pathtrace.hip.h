@@ -227,19 +227,18 @@ __device__ __forceinline__ void setup_surface(const DevScene& S, PathState& p, b
                                               uint32_t galbedo) {
   InvRows m = load_inv_rows(S, p.inst);
   Bary b = barycentrics(S, p.tri, mul_point(m, p.ro), mul_dir(m, p.rd));
-  float4 tidx = S.topo[5 * p.tri];
-  uint32_t i0 = rt_f2u(tidx.x), i1 = rt_f2u(tidx.y), i2 = rt_f2u(tidx.z);
-  float2 uv0 = S.uv[i0], uv1 = S.uv[i1], uv2 = S.uv[i2];
-  p.tex_uv = rt2_make(uv0.x, uv0.y) * b.w + rt2_make(uv1.x, uv1.y) * b.u + rt2_make(uv2.x, uv2.y) * b.v;
+  const float4* ts = S.tri_shade + 8 * (size_t)p.tri;   // the hit's shading record: one 128-byte line
+  const float4 q4 = ts[4], q5 = ts[5], q6 = ts[6], q7 = ts[7];
+  p.tex_uv = rt2_make(q4.w, q5.w) * b.w + rt2_make(q6.w, q7.x) * b.u + rt2_make(q7.y, q7.z) * b.v;
   if (from_gbuffer) {
     p.hit_t = b.t;
     p.normal = unpack_normal(gx, gy);
     p.albedo = rt3_make(rt_from_unorm8(galbedo & 255u), rt_from_unorm8((galbedo >> 8) & 255u),
                         rt_from_unorm8((galbedo >> 16) & 255u));
   } else {
-    rt3 ln = rt_normalize(xyz(S.nrm[i0]) * b.w + xyz(S.nrm[i1]) * b.u + xyz(S.nrm[i2]) * b.v);
+    rt3 ln = rt_normalize(xyz(q4) * b.w + xyz(q5) * b.u + xyz(q6) * b.v);
     p.normal = rt_normalize(normal_to_world(m, ln));
-    float4 nd0 = S.topo[5 * p.tri + 1], nd2 = S.topo[5 * p.tri + 3];
+    float4 nd0 = ts[0], nd2 = ts[2];
     p.albedo = xyz(nd0);
     if (nd2.x > -0.5f) p.albedo = p.albedo * sample_tex(S, p.tex_uv, rt_f2i32_sat(nd2.x));
     if (nd2.z > -0.5f) {
@@ -266,7 +265,8 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
   o.want_shadow = o.want_extend = o.nee_valid = false;
   o.sh_o = o.sh_d = o.nee = rt3_splat(0.0f);
   o.sh_tmax = 0.0f;
-  float4 d0 = S.topo[5 * p.tri + 1], d1 = S.topo[5 * p.tri + 2], d2 = S.topo[5 * p.tri + 3], d3 = S.topo[5 * p.tri + 4];
+  const float4* ts = S.tri_shade + 8 * (size_t)p.tri;
+  float4 d0 = ts[0], d1 = ts[1], d2 = ts[2], d3 = ts[3];
   const uint32_t mat_type = rt_f2u32_sat(d0.w + 0.5f);
   const rt3 hit_p = p.ro + p.rd * p.hit_t;
   p.normal = (rt_dot(p.rd, p.normal) < 0.0f) ? p.normal : -p.normal;
@@ -363,8 +363,11 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
 // number of 16-byte LDS slots the whole scene needs (traversal records + shading arrays)
 __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts,
                                                   uint32_t n_lights) {
-  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + ((size_t)n_inst + 3) / 4 + (size_t)5 * n_tris +
-         (size_t)2 * n_verts + ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 + (size_t)4 * n_lights;
+  // tnodes, tri_geom, inst_trav, inst_root | tri_shade | topo, pos, uv (light_pdf / light sampling of emissive hits), inst,
+  // lights, light_rec
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + ((size_t)n_inst + 3) / 4 + (size_t)8 * n_tris +
+         (size_t)5 * n_tris + (size_t)n_verts + ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 +
+         (size_t)4 * n_lights;
 }
 
 // Diagnostic build only (-DRT_CLOCK_STAMP, tools/clock_check.py): every workgroup of the persistent kernel stamps
@@ -463,9 +466,9 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     f4* li = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
     M.l_root = slot;
     stage(Sg.inst_root, ((size_t)n_inst_total + 3) / 4);
+    S.tri_shade = reinterpret_cast<const float4*>(stage(Sg.tri_shade, (size_t)8 * n_tris_total));
     S.topo = reinterpret_cast<const float4*>(stage(Sg.topo, (size_t)5 * n_tris_total));
-    S.pos = reinterpret_cast<const float4*>(stage(Sg.pos, n_verts_total));
-    S.nrm = reinterpret_cast<const float4*>(stage(Sg.nrm, n_verts_total));
+    S.pos = reinterpret_cast<const float4*>(stage(Sg.pos, n_verts_total));   // S.nrm stays in global memory: no reader left here
     // uv (8 B/vertex) and lights (8 B each): the device buffers are allocated with >= 16-byte slack
     S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));
     S.inst = reinterpret_cast<const float4*>(stage(Sg.inst, (size_t)9 * n_inst_total));

@@ -21,6 +21,29 @@ __global__ void k_prepare_tris(const float4* __restrict__ topo, const float4* __
   tri_geom[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
   tri_geom[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
 }
+// per-triangle shading record (device_scene.h): pure copies
+__global__ void k_prepare_tri_shade(const float4* __restrict__ topo, const float4* __restrict__ nrm,
+                                    const float2* __restrict__ uv, float4* __restrict__ tri_shade, uint32_t n_tris,
+                                    uint32_t n_verts) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tris) return;
+  float4 idx = topo[5 * i];
+  uint32_t i0 = rt_f2u(idx.x), i1 = rt_f2u(idx.y), i2 = rt_f2u(idx.z);
+  if (i0 >= n_verts) i0 = n_verts - 1;  // robust buffer access: clamp instead of faulting
+  if (i1 >= n_verts) i1 = n_verts - 1;
+  if (i2 >= n_verts) i2 = n_verts - 1;
+  const float4 n0 = nrm[i0], n1 = nrm[i1], n2 = nrm[i2];
+  const float2 t0 = uv[i0], t1 = uv[i1], t2 = uv[i2];
+  float4* dst = tri_shade + 8 * (size_t)i;
+  dst[0] = topo[5 * i + 1];
+  dst[1] = topo[5 * i + 2];
+  dst[2] = topo[5 * i + 3];
+  dst[3] = topo[5 * i + 4];
+  dst[4] = make_float4(n0.x, n0.y, n0.z, t0.x);
+  dst[5] = make_float4(n1.x, n1.y, n1.z, t0.y);
+  dst[6] = make_float4(n2.x, n2.y, n2.z, t1.x);
+  dst[7] = make_float4(t1.y, t2.x, t2.y, 0.0f);
+}
 __global__ void k_prepare_lights(DevScene S, float4* __restrict__ light_rec, uint32_t n, uint32_t n_tris,
                                  uint32_t n_inst) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,9 +74,9 @@ __global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __r
 }
 
 // ================================================================ primary visibility
-// 16-byte LDS slots of the records this kernel reads (nodes, triangle records, instance rows, topology, normals, uvs)
-__host__ __device__ inline size_t primary_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t n_verts) {
-  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)5 * n_tris + (size_t)n_verts + ((size_t)n_verts + 1) / 2;
+// 16-byte LDS slots of the records this kernel reads (nodes, triangle records, instance rows, per-triangle shading records)
+__host__ __device__ inline size_t primary_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t /*n_verts*/) {
+  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)8 * n_tris;
 }
 
 // LDS = false: one wave (one 8x8 tile) per workgroup, records through L1 / L2.  LDS = true (small scenes): four tiles per
@@ -78,9 +101,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void k_primary_visibility(DevScene 
     S.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
     S.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
     S.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
-    S.topo = stage(Sg.topo, (size_t)5 * n_tris_total);
-    S.nrm = stage(Sg.nrm, n_verts_total);
-    S.uv = reinterpret_cast<const float2*>(stage(Sg.uv, ((size_t)n_verts_total + 1) / 2));  // >= 16 B of slack behind uv
+    S.tri_shade = stage(Sg.tri_shade, (size_t)8 * n_tris_total);
     __syncthreads();
   }
   const uint32_t tile_id = LDS ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x;
@@ -131,17 +152,16 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void k_primary_visibility(DevScene 
     } else {
       InvRows m = load_inv_rows(S, (uint32_t)hit.inst);
       Bary b = barycentrics(S, (uint32_t)hit.tri, mul_point(m, eye), mul_dir(m, d));
-      float4 idx = S.topo[5 * hit.tri], d0 = S.topo[5 * hit.tri + 1], d2 = S.topo[5 * hit.tri + 3];
-      uint32_t i0 = rt_f2u(idx.x), i1 = rt_f2u(idx.y), i2 = rt_f2u(idx.z);
-      rt3 wn0 = rt_normalize(normal_to_world(m, xyz(S.nrm[i0])));
-      rt3 wn1 = rt_normalize(normal_to_world(m, xyz(S.nrm[i1])));
-      rt3 wn2 = rt_normalize(normal_to_world(m, xyz(S.nrm[i2])));
+      const float4* ts = S.tri_shade + 8 * (size_t)hit.tri;
+      const float4 d0 = ts[0], d2 = ts[2], q4 = ts[4], q5 = ts[5], q6 = ts[6], q7 = ts[7];
+      rt3 wn0 = rt_normalize(normal_to_world(m, xyz(q4)));
+      rt3 wn1 = rt_normalize(normal_to_world(m, xyz(q5)));
+      rt3 wn2 = rt_normalize(normal_to_world(m, xyz(q6)));
       rt3 n = rt_normalize(wn0 * b.w + wn1 * b.u + wn2 * b.v);
       rt2 pn = pack_normal(n);
       rt3 albedo = xyz(d0);
       if (d2.x > -0.5f) {
-        float2 a0 = S.uv[i0], a1 = S.uv[i1], a2 = S.uv[i2];
-        rt2 tuv = rt2_make(a0.x, a0.y) * b.w + rt2_make(a1.x, a1.y) * b.u + rt2_make(a2.x, a2.y) * b.v;
+        rt2 tuv = rt2_make(q4.w, q5.w) * b.w + rt2_make(q6.w, q7.x) * b.u + rt2_make(q7.y, q7.z) * b.v;
         albedo = albedo * sample_tex(S, tuv, rt_f2i32_sat(d2.x));
       }
       F.albedo[p_idx] = rt_unorm8(albedo.x) | (rt_unorm8(albedo.y) << 8) | (rt_unorm8(albedo.z) << 16) | (255u << 24);

@@ -75,7 +75,10 @@ __device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, con
 // host launches one more pass after the last depth for those.  The trace kernels therefore never touch the path state:
 // they stream their queue in and their results out.
 template <bool FIRST, bool DETAIL>
-__global__ __launch_bounds__(256) void k_wf_shade(DevScene S, DevFrame F, rt_scene_uniforms U, WfState W, WfQueues Q,
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, DevFrame F, rt_scene_uniforms U, WfState W, WfQueues Q,
                                                   const DevFrameSlot* __restrict__ slots, uint32_t n_slots,
                                                   uint32_t depth) {
   const uint32_t npx = U.width * U.height;

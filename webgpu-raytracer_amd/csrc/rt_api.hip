@@ -53,7 +53,7 @@ struct rt_ctx {
   void* bv_pinned = nullptr;  // 64 KB of pinned host memory for the per-level read-backs of rt_build_blas
   DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
   // derived buffers (device_scene.h)
-  DeviceBuffer tri_geom, inst_trav, light_rec;
+  DeviceBuffer tri_geom, tri_shade, inst_trav, light_rec;
   DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w;   // k_treelet.hip.h
   std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true;
@@ -269,6 +269,12 @@ int prepare_scene(rt_ctx* c) {
                        (const float4*)c->topology.ptr, (const float4*)c->pos.ptr, (float4*)c->tri_geom.ptr,
                        c->n_tris, c->n_verts);
     HIP_TRY(c, hipGetLastError());
+    r = ensure_buffer(c, c->tri_shade, (size_t)c->n_tris * 128, true);
+    if (r < 0) return r;
+    hipLaunchKernelGGL(rtk::k_prepare_tri_shade, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream,
+                       (const float4*)c->topology.ptr, (const float4*)c->nrm.ptr, (const float2*)c->uv.ptr,
+                       (float4*)c->tri_shade.ptr, c->n_tris, c->n_verts);
+    HIP_TRY(c, hipGetLastError());
     c->tris_dirty = false;
   }
   if (c->inst_dirty && c->n_instances) {
@@ -336,6 +342,7 @@ DevScene dev_scene(const rt_ctx* c) {
   s.tnodes = (const float4*)c->tnodes.ptr;
   s.inst_root = (const uint32_t*)c->inst_root.ptr;
   s.tri_geom = (const float4*)c->tri_geom.ptr;
+  s.tri_shade = (const float4*)c->tri_shade.ptr;
   s.inst_trav = (const float4*)c->inst_trav.ptr;
   s.topo = (const float4*)c->topology.ptr;
   s.pos = (const float4*)c->pos.ptr;
@@ -444,7 +451,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DeviceBuffer* all[] = {&c->topology, &c->instances, &c->lights, &c->draw_commands, &c->pos, &c->nrm, &c->uv,
-                         &c->nodes, &c->textures, &c->tri_geom, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
+                         &c->nodes, &c->textures, &c->tri_geom, &c->tri_shade, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
