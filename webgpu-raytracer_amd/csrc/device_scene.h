@@ -29,11 +29,17 @@
 #include "../../include/mi355rt_layout.h"
 #include "../../include/mi355rt_math.h"
 
+// 16-byte slots per triangle record.  4 (one aligned 64-byte line per triangle; a 48-byte record straddles two lines
+// 37 % of the time) was measured: no gain on any scene, 33 % more memory
+#ifndef RT_TRI_STRIDE
+#define RT_TRI_STRIDE 3
+#endif
+
 struct DevScene {
   const float4* nodes;      // 2 per node, TLAS ++ BLAS (bridge layout; the per-lane walks of the primary pass read it)
   const float4* tnodes;     // 2 per node: the same nodes with explicit successors, treelet first (k_treelet.hip.h)
   const uint32_t* inst_root;  // 1 per instance: index in tnodes of the instance's BLAS root
-  const float4* tri_geom;   // 3 per triangle
+  const float4* tri_geom;   // RT_TRI_STRIDE per triangle: {v0} {e1} {e2} (+ padding to one 64-byte line)
   const float4* tri_shade;  // 8 per triangle: what shading reads about a hit, in ONE 128-byte line
   const float4* inst_trav;  // 4 per instance
   const float4* topo;       // 5 per triangle (raw MeshTopology rows)

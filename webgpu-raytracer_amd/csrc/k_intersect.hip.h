@@ -90,7 +90,7 @@ __device__ Hit trace_closest(const DevScene& S, uint32_t blas_base, rt3 o, rt3 d
               for (uint32_t i = 0; i < count; i++) {
                 uint32_t tri = first + i;
                 if (COUNT) c.tris++;
-                float t = hit_tri(S.tri_geom[3 * tri], S.tri_geom[3 * tri + 1], S.tri_geom[3 * tri + 2], rl, t_min,
+                float t = hit_tri(S.tri_geom[RT_TRI_STRIDE * tri], S.tri_geom[RT_TRI_STRIDE * tri + 1], S.tri_geom[RT_TRI_STRIDE * tri + 2], rl, t_min,
                                   closest);
                 if (t > 0.0f) {
                   closest = t;
@@ -149,7 +149,7 @@ __device__ bool trace_any(const DevScene& S, uint32_t blas_base, rt3 o, rt3 d, f
               for (uint32_t i = 0; i < count; i++) {
                 uint32_t tri = first + i;
                 if (COUNT) c.tris++;
-                float t = hit_tri(S.tri_geom[3 * tri], S.tri_geom[3 * tri + 1], S.tri_geom[3 * tri + 2], rl, t_min,
+                float t = hit_tri(S.tri_geom[RT_TRI_STRIDE * tri], S.tri_geom[RT_TRI_STRIDE * tri + 1], S.tri_geom[RT_TRI_STRIDE * tri + 2], rl, t_min,
                                   t_max);
                 if (t > 0.0f) return true;
               }

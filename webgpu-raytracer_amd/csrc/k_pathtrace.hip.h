@@ -365,7 +365,7 @@ __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_t
                                                   uint32_t n_lights) {
   // tnodes, tri_geom, inst_trav, inst_root | tri_shade | topo, pos, uv (light_pdf / light sampling of emissive hits), inst,
   // lights, light_rec
-  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + ((size_t)n_inst + 3) / 4 + (size_t)8 * n_tris +
+  return (size_t)2 * n_nodes + (size_t)RT_TRI_STRIDE * n_tris + (size_t)4 * n_inst + ((size_t)n_inst + 3) / 4 + (size_t)8 * n_tris +
          (size_t)5 * n_tris + (size_t)n_verts + ((size_t)n_verts + 1) / 2 + (size_t)9 * n_inst + ((size_t)n_lights + 1) / 2 +
          (size_t)4 * n_lights;
 }
@@ -414,8 +414,8 @@ __device__ __forceinline__ uint32_t trav_stage_mixed(TravMem& M, f4* lds, uint32
   }
   if (P.stage_tri) {
     M.l_tri = slot;
-    lds_stage(lds + slot, Sg.tri_geom, (size_t)3 * n_tris_total);
-    slot += 3u * n_tris_total;
+    lds_stage(lds + slot, Sg.tri_geom, (size_t)RT_TRI_STRIDE * n_tris_total);
+    slot += (uint32_t)RT_TRI_STRIDE * n_tris_total;
   }
   return slot - slot0;
 }
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     M.l_nodes = slot;
     f4* ln = stage(Sg.tnodes, (size_t)2 * n_nodes_total);
     M.l_tri = slot;
-    f4* lt = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    f4* lt = stage(Sg.tri_geom, (size_t)RT_TRI_STRIDE * n_tris_total);
     M.l_inst = slot;
     f4* li = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
     M.l_root = slot;

@@ -17,9 +17,9 @@ __global__ void k_prepare_tris(const float4* __restrict__ topo, const float4* __
   if (i2 >= n_verts) i2 = n_verts - 1;
   rt3 v0 = xyz(pos[i0]), v1 = xyz(pos[i1]), v2 = xyz(pos[i2]);
   rt3 e1 = v1 - v0, e2 = v2 - v0;
-  tri_geom[3 * i + 0] = make_float4(v0.x, v0.y, v0.z, 0.0f);
-  tri_geom[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-  tri_geom[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+  tri_geom[RT_TRI_STRIDE * i + 0] = make_float4(v0.x, v0.y, v0.z, 0.0f);
+  tri_geom[RT_TRI_STRIDE * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+  tri_geom[RT_TRI_STRIDE * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
 }
 // per-triangle shading record (device_scene.h): pure copies
 __global__ void k_prepare_tri_shade(const float4* __restrict__ topo, const float4* __restrict__ nrm,
@@ -76,7 +76,7 @@ __global__ void k_prepare_instances(const float4* __restrict__ inst, float4* __r
 // ================================================================ primary visibility
 // 16-byte LDS slots of the records this kernel reads (nodes, triangle records, instance rows, per-triangle shading records)
 __host__ __device__ inline size_t primary_lds_slots(uint32_t n_nodes, uint32_t n_tris, uint32_t n_inst, uint32_t /*n_verts*/) {
-  return (size_t)2 * n_nodes + (size_t)3 * n_tris + (size_t)4 * n_inst + (size_t)8 * n_tris;
+  return (size_t)2 * n_nodes + (size_t)RT_TRI_STRIDE * n_tris + (size_t)4 * n_inst + (size_t)8 * n_tris;
 }
 
 // LDS = false: one wave (one 8x8 tile) per workgroup, records through L1 / L2.  LDS = true (small scenes): four tiles per
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void k_primary_visibility(DevScene 
       return base;
     };
     S.nodes = stage(Sg.nodes, (size_t)2 * n_nodes_total);
-    S.tri_geom = stage(Sg.tri_geom, (size_t)3 * n_tris_total);
+    S.tri_geom = stage(Sg.tri_geom, (size_t)RT_TRI_STRIDE * n_tris_total);
     S.inst_trav = stage(Sg.inst_trav, (size_t)4 * n_inst_total);
     S.tri_shade = stage(Sg.tri_shade, (size_t)8 * n_tris_total);
     __syncthreads();

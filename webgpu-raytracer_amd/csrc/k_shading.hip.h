@@ -22,10 +22,10 @@ struct Bary {
 };
 // unbounded ray/plane barycentrics of the local-space ray against triangle `tri` (:632-643)
 __device__ __forceinline__ Bary barycentrics(const DevScene& S, uint32_t tri, rt3 lo, rt3 ld) {
-  rt3 v0 = xyz(S.tri_geom[3 * tri]);
+  rt3 v0 = xyz(S.tri_geom[RT_TRI_STRIDE * tri]);
   Bary b;
-  b.e1 = xyz(S.tri_geom[3 * tri + 1]);
-  b.e2 = xyz(S.tri_geom[3 * tri + 2]);
+  b.e1 = xyz(S.tri_geom[RT_TRI_STRIDE * tri + 1]);
+  b.e2 = xyz(S.tri_geom[RT_TRI_STRIDE * tri + 2]);
   rt3 s = lo - v0;
   rt3 h = rt_cross(ld, b.e2);
   float f = 1.0f / rt_dot(b.e1, h);

@@ -251,13 +251,13 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
       q.d = rt3_make(rb.x, rb.y, rb.z);
       f4 g0, g1, g2;
       if (tri_lds) {
-        g0 = ld_l(lds, M.l_tri + 3u * tri);
-        g1 = ld_l(lds, M.l_tri + 3u * tri + 1u);
-        g2 = ld_l(lds, M.l_tri + 3u * tri + 2u);
+        g0 = ld_l(lds, M.l_tri + (uint32_t)RT_TRI_STRIDE * tri);
+        g1 = ld_l(lds, M.l_tri + (uint32_t)RT_TRI_STRIDE * tri + 1u);
+        g2 = ld_l(lds, M.l_tri + (uint32_t)RT_TRI_STRIDE * tri + 2u);
       } else {
-        g0 = ld_g(M.gtri, 3 * (size_t)tri);
-        g1 = ld_g(M.gtri, 3 * (size_t)tri + 1);
-        g2 = ld_g(M.gtri, 3 * (size_t)tri + 2);
+        g0 = ld_g(M.gtri, RT_TRI_STRIDE * (size_t)tri);
+        g1 = ld_g(M.gtri, RT_TRI_STRIDE * (size_t)tri + 1);
+        g2 = ld_g(M.gtri, RT_TRI_STRIDE * (size_t)tri + 2);
       }
       float t;
       bool ok = hit_tri_nb(g0, g1, g2, q, ra.w, rb.w, t);

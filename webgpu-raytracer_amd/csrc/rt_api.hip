@@ -263,7 +263,7 @@ int prepare_scene(rt_ctx* c) {
     if (r < 0) return r;
   }
   if (c->tris_dirty && c->n_tris && c->n_verts) {
-    int r = ensure_buffer(c, c->tri_geom, (size_t)c->n_tris * 48, true);
+    int r = ensure_buffer(c, c->tri_geom, (size_t)c->n_tris * 16 * RT_TRI_STRIDE, true);
     if (r < 0) return r;
     hipLaunchKernelGGL(rtk::k_prepare_tris, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream,
                        (const float4*)c->topology.ptr, (const float4*)c->pos.ptr, (float4*)c->tri_geom.ptr,
@@ -884,7 +884,7 @@ static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes,
   if (c->treelet_cap >= 0) k = std::min<size_t>(k, (size_t)c->treelet_cap);   // MI355RT_TREELET_MAX (experiments)
   P.k_nodes = (uint32_t)k;
   avail -= k * 32;
-  const size_t tri_bytes = (size_t)c->n_tris * 48;
+  const size_t tri_bytes = (size_t)c->n_tris * 16 * RT_TRI_STRIDE;
   if (tri_bytes <= avail) {
     P.stage_tri = 1;
     avail -= tri_bytes;
@@ -944,7 +944,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
   // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
   // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
-  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)3 * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
+  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
   const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
   if (!trace_lds) {
