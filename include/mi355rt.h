@@ -189,6 +189,10 @@ int rt_kernel_times(rt_ctx* ctx, double* sum_ms, uint32_t* launches, uint32_t n)
  * k_pathtrace_persistent launch (in-kernel clock = ratio x 100 MHz).  Returns the number of pairs written, 0 in the
  * product build, where no stamp executes. */
 int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
+/* The derived traversal array of the uploaded scene (csrc/k_treelet.hip.h) for tests: 8 f32 per node in the new order,
+ * the original-index -> new-index table, and the per-instance BLAS roots (any pointer may be NULL).  Returns the node count. */
+int rt_debug_read_traversal_nodes(rt_ctx* ctx, float* tnodes_out, uint32_t* new_index_out, uint32_t* inst_root_out,
+                                  uint32_t cap_nodes);
 /* Diagnostic build (-DRT_TRACE_STAMPS) only: s_memtime cycles the waves of k_wf_trace spent in its three sections,
  * summed over all launches since the last reset: out16[queue][k], queue 0 = closest hit, 1 = any hit; k = 0..2 cycles in
  * {retire / pull, node step, triangle flush}, 3..5 how often each did work, 6 waves, 7 loop trips.  Returns 1 in the

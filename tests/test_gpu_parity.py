@@ -482,3 +482,54 @@ def test_malformed_scene_arrays_are_refused_not_followed(W, gpu_renderer):
     r.updateBuffer("lights", b.lights)
     r.compute(2)                                                   # the intact scene renders again
     r.sync()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "viewer_diamond", "mixed", "instanced1000", "sponza_like", "glass_blob"])
+def test_traversal_array_is_the_same_tree_renumbered(W, gpu_renderer, scene):
+    """tnodes (csrc/k_treelet.hip.h): a permutation of the bridge's nodes with both successors explicit. Following them
+    from the roots must walk every BLAS and the TLAS in the ORIGINAL pre-order, with the original boxes and leaf words;
+    the largest-area nodes come first."""
+    import ctypes
+    b = pu.bridge_for(W, scene)
+    r = gpu_renderer
+    r.buildPipeline(4, 1)
+    W.upload_scene(r, b, 32, 16)
+    tl, bl = np.asarray(b.tlas, np.float32).reshape(-1, 8), np.asarray(b.blas, np.float32).reshape(-1, 8)
+    nodes = np.concatenate([tl, bl])
+    n, n_tlas = len(nodes), len(tl)
+    inst = np.asarray(b.instances, np.float32).reshape(-1, 36).view(np.uint32)
+    tn = np.zeros((n, 8), np.float32)
+    new = np.zeros(n, np.uint32)
+    roots = np.zeros(len(inst), np.uint32)
+    vp = ctypes.c_void_p
+    got = r.L.rt_debug_read_traversal_nodes(r.ctx, tn.ctypes.data_as(vp), new.ctypes.data_as(vp), roots.ctypes.data_as(vp), n)
+    assert got == n
+    assert sorted(new.tolist()) == list(range(n)) and new[0] == 0           # a permutation; the TLAS root stays node 0
+    u, tu = nodes.view(np.uint32), tn.view(np.uint32)
+    END, INNER = 0xffffffff, 0x80000000
+    # boxes travel with their node; leaves keep their word; inner nodes point at their first child, skips at the original target
+    assert np.array_equal(tu[new][:, [0, 1, 2, 4, 5, 6]], u[:, [0, 1, 2, 4, 5, 6]])
+    leaf = u[:, 7] != 0
+    assert np.array_equal(tu[new[leaf], 7], u[leaf, 7])
+    inner = np.flatnonzero(~leaf)
+    reach = np.zeros(n, bool)           # nodes inside a TLAS / BLAS range that a walk can reach
+    reach[:int(u[0, 3])] = True
+    skip_target = np.full(n, -1, np.int64)
+    skip_target[:n_tlas] = np.where(u[:n_tlas, 3] < u[0, 3], u[:n_tlas, 3].astype(np.int64), -1)
+    for off in sorted(set(inst[:, 32].tolist())):
+        root = n_tlas + off
+        end = root + int(u[root, 3])
+        reach[root:end] = True
+        tgt = root + u[root:end, 3].astype(np.int64)
+        skip_target[root:end] = np.where(tgt < end, tgt, -1)
+    ri = inner[reach[inner]]
+    assert np.array_equal(tu[new[ri], 7], INNER | new[ri + 1])
+    rr = np.flatnonzero(reach)
+    expect = np.where(skip_target[rr] >= 0, new[np.maximum(skip_target[rr], 0)], END).astype(np.uint32)
+    assert np.array_equal(tu[new[rr], 3], expect)
+    assert np.array_equal(roots, new[n_tlas + inst[:, 32]])
+    # treelet first: the head of the array holds the largest boxes (single-BLAS scenes: the weight is the box area)
+    if scene == "sponza_like":
+        ext = tn[:, 4:7] - tn[:, 0:3]
+        area = 2 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0])
+        assert int((area[:5120] >= area[5120:].max()).sum()) >= 4000

@@ -63,85 +63,142 @@ __global__ __launch_bounds__(256) void k_treelet_weight(TreeletArgs A) {
   A.key[i] = k;
 }
 
-// One workgroup: pick a key threshold such that at most k_max nodes lie at or above it (two 4096-bin histogram levels:
-// the top 24 bits of the key), then number the nodes — selected ones first, in original order; the others after them,
-// in original order as well.
-__global__ __launch_bounds__(1024) void k_treelet_order(TreeletArgs A) {
-  __shared__ uint32_t hist[4096];
-  __shared__ uint32_t s_bin, s_above, s_scan[1024], s_base_sel, s_base_rest, s_total_sel;
+// Numbering in seven small launches (one workgroup doing everything took 0.5 ms for 110 k nodes, which an animated scene
+// would pay on every update):
+//   k_treelet_hist<0>, k_treelet_pick<0>   4096-bin histogram of the keys' top 12 bits; the bin that does not fit k_max whole
+//   k_treelet_hist<1>, k_treelet_pick<1>   the same inside that bin on the next 12 bits -> key threshold (24 bits deep)
+//   k_treelet_count, k_treelet_blockscan, k_treelet_number
+//                                          selected nodes (key >= threshold) are numbered first, in original order, the
+//                                          others after them in original order: per-1024-node block counts, their scan,
+//                                          ballot ranks inside a block
+// work: [0, 4096) level-0 histogram, [4096, 8192) level-1 histogram, then the TreeletPick words, then one count per block.
+struct TreeletPick {
+  uint32_t bin0, above0, threshold, total_sel, all, pad[3];
+};
+#define RT_TREELET_WORK_HEAD (8192u + 8u)
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_treelet_hist(TreeletArgs A, uint32_t* __restrict__ work) {
+  __shared__ uint32_t s_hist[4096];
+  for (uint32_t b = threadIdx.x; b < 4096u; b += 256u) s_hist[b] = 0u;
+  __syncthreads();
+  const TreeletPick* P = reinterpret_cast<const TreeletPick*>(work + 8192);
+  const uint32_t bin0 = LEVEL == 0 ? 0u : P->bin0;
+  if (LEVEL == 1 && P->all) return;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < A.n_nodes; i += gridDim.x * 256u) {
+    const uint32_t k = A.key[i];
+    if (LEVEL == 0) atomicAdd(&s_hist[k >> 20], 1u);
+    else if ((k >> 20) == bin0) atomicAdd(&s_hist[(k >> 8) & 4095u], 1u);
+  }
+  __syncthreads();
+  uint32_t* hist = work + (LEVEL == 0 ? 0u : 4096u);
+  for (uint32_t b = threadIdx.x; b < 4096u; b += 256u)
+    if (s_hist[b]) atomicAdd(&hist[b], s_hist[b]);
+}
+
+// one workgroup of 256 threads: walk the 4096 bins from the top until the count would exceed k_max
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_treelet_pick(TreeletArgs A, uint32_t* __restrict__ work) {
+  __shared__ uint32_t s_part[256];
+  TreeletPick* P = reinterpret_cast<TreeletPick*>(work + 8192);
+  if (LEVEL == 1 && P->all) return;
+  const uint32_t* hist = work + (LEVEL == 0 ? 0u : 4096u);
   const uint32_t t = threadIdx.x;
-  uint32_t threshold = 0u;
-  for (int level = 0; level < 2; level++) {
-    for (uint32_t b = t; b < 4096u; b += 1024u) hist[b] = 0u;
+  // thread t owns bins [4080 - 16 t, 4096 - 16 t): thread 0 the topmost sixteen
+  const uint32_t top = 4096u - 16u * t;
+  uint32_t sum = 0u;
+  for (uint32_t k = 0; k < 16u; k++) sum += hist[top - 1u - k];
+  s_part[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1u; off < 256u; off <<= 1) {
+    const uint32_t v = t >= off ? s_part[t - off] : 0u;
     __syncthreads();
-    const uint32_t prefix_bin = level == 0 ? 0u : s_bin;
-    for (uint32_t i = t; i < A.n_nodes; i += 1024u) {
-      const uint32_t k = A.key[i];
-      if (level == 0) atomicAdd(&hist[k >> 20], 1u);
-      else if ((k >> 20) == prefix_bin) atomicAdd(&hist[(k >> 8) & 4095u], 1u);
-    }
-    __syncthreads();
-    if (t == 0u) {
-      // walk the bins from the top: stop at the first bin that would take the count above k_max
-      uint32_t above = level == 0 ? 0u : s_above;
-      int b = 4095;
-      for (; b >= 0; b--) {
-        if (above + hist[b] > A.k_max) break;
-        above += hist[b];
-      }
-      s_above = above;                       // nodes strictly above bin b (they are all selected)
-      s_bin = b < 0 ? 0u : (uint32_t)b;      // the bin that does not fit as a whole
-      if (b < 0) s_bin = 0xffffffffu;        // everything fits
-    }
-    __syncthreads();
-    if (s_bin == 0xffffffffu) {
-      threshold = 0u;                        // select every node
-      break;
-    }
-    if (level == 0) threshold = (s_bin + 1u) << 20;            // provisional: all bins above the one that overflows
-    else threshold = (prefix_bin << 20) | ((s_bin + 1u) << 8);  // refined inside that bin
-    if (level == 1 && s_bin == 4095u) threshold = (prefix_bin + 1u) << 20;
+    s_part[t] += v;
     __syncthreads();
   }
-  // numbering: chunked exclusive scan of the selection flags
-  if (t == 0u) {
-    s_base_sel = 0u;
-    s_base_rest = 0u;
+  const uint32_t base = LEVEL == 0 ? 0u : P->above0;
+  const uint32_t before = base + s_part[t] - sum;   // nodes in all bins above this thread's sixteen
+  const uint32_t total = base + s_part[255];
+  __syncthreads();
+  if (LEVEL == 0 && t == 0u) {
+    P->all = total <= A.k_max ? 1u : 0u;
+    if (total <= A.k_max) {
+      P->threshold = 0u;
+      P->total_sel = total;
+    }
   }
-  __syncthreads();
-  // first pass: count the selected nodes (needed for the base of the others)
-  uint32_t mine = 0u;
-  for (uint32_t i = t; i < A.n_nodes; i += 1024u) mine += (A.key[i] >= threshold && threshold != 0u) || threshold == 0u ? 1u : 0u;
-  s_scan[t] = mine;
-  __syncthreads();
-  for (uint32_t off = 512u; off > 0u; off >>= 1) {
-    if (t < off) s_scan[t] += s_scan[t + off];
-    __syncthreads();
+  if (total <= A.k_max) return;
+  if (before <= A.k_max && before + sum > A.k_max) {   // the overflowing bin is one of mine: exactly one thread gets here
+    uint32_t above = before;
+    uint32_t b = top - 1u;
+    for (uint32_t k = 0; k < 16u; k++, b--) {
+      if (above + hist[b] > A.k_max) break;
+      above += hist[b];
+    }
+    if (LEVEL == 0) {
+      P->bin0 = b;
+      P->above0 = above;
+    } else {
+      P->threshold = (P->bin0 << 20) + ((b + 1u) << 8);   // keys >= threshold: every bin above bin0, and inside it the sub-bins above b
+      P->total_sel = above;
+    }
   }
-  if (t == 0u) s_total_sel = s_scan[0];
+}
+
+__device__ __forceinline__ bool treelet_selected(const TreeletArgs& A, const TreeletPick* P, uint32_t i) {
+  return i < A.n_nodes && (P->all != 0u || A.key[i] >= P->threshold);
+}
+__global__ __launch_bounds__(1024) void k_treelet_count(TreeletArgs A, uint32_t* __restrict__ work) {
+  __shared__ uint32_t s_cnt;
+  const TreeletPick* P = reinterpret_cast<const TreeletPick*>(work + 8192);
+  if (threadIdx.x == 0u) s_cnt = 0u;
   __syncthreads();
-  const uint32_t total_sel = s_total_sel;
-  for (uint32_t c0 = 0u; c0 < A.n_nodes; c0 += 1024u) {
-    const uint32_t i = c0 + t;
-    const bool valid = i < A.n_nodes;
-    const bool sel = valid && (threshold == 0u || A.key[i] >= threshold);
-    s_scan[t] = sel ? 1u : 0u;
+  const bool sel = treelet_selected(A, P, blockIdx.x * 1024u + threadIdx.x);
+  const unsigned long long m = __ballot(sel);
+  if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(m));
+  __syncthreads();
+  if (threadIdx.x == 0u) work[RT_TREELET_WORK_HEAD + blockIdx.x] = s_cnt;
+}
+// exclusive scan of the per-block counts, in place (one workgroup; n_blocks is small: 1 per 1024 nodes)
+__global__ __launch_bounds__(1024) void k_treelet_blockscan(uint32_t* __restrict__ work, uint32_t n_blocks) {
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_carry;
+  uint32_t* cnt = work + RT_TREELET_WORK_HEAD;
+  if (threadIdx.x == 0u) s_carry = 0u;
+  __syncthreads();
+  for (uint32_t c0 = 0u; c0 < n_blocks; c0 += 1024u) {
+    const uint32_t i = c0 + threadIdx.x;
+    const uint32_t v = i < n_blocks ? cnt[i] : 0u;
+    s_scan[threadIdx.x] = v;
     __syncthreads();
-    for (uint32_t off = 1u; off < 1024u; off <<= 1) {   // Hillis-Steele inclusive scan
-      const uint32_t v = t >= off ? s_scan[t - off] : 0u;
+    for (uint32_t off = 1u; off < 1024u; off <<= 1) {
+      const uint32_t w = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
       __syncthreads();
-      s_scan[t] += v;
+      s_scan[threadIdx.x] += w;
       __syncthreads();
     }
-    const uint32_t incl = s_scan[t], excl = incl - (sel ? 1u : 0u);
-    if (valid) A.new_index[i] = sel ? s_base_sel + excl : total_sel + s_base_rest + (t - excl);
+    if (i < n_blocks) cnt[i] = s_carry + s_scan[threadIdx.x] - v;
     __syncthreads();
-    if (t == 1023u) {
-      s_base_sel += incl;
-      s_base_rest += 1024u - incl;   // only consulted for later chunks, whose nodes are all valid up to the last one
-    }
+    if (threadIdx.x == 1023u) s_carry += s_scan[1023];
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(1024) void k_treelet_number(TreeletArgs A, const uint32_t* __restrict__ work) {
+  __shared__ uint32_t s_wave[16];
+  const TreeletPick* P = reinterpret_cast<const TreeletPick*>(work + 8192);
+  const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+  const bool sel = treelet_selected(A, P, i);
+  const unsigned long long m = __ballot(sel);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t rank_in_wave = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  if (lane == 0u) s_wave[wave] = (uint32_t)__builtin_popcountll(m);
+  __syncthreads();
+  uint32_t before = 0u;   // selected nodes of this block in earlier waves
+  for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+  if (i >= A.n_nodes) return;
+  const uint32_t sel_before = work[RT_TREELET_WORK_HEAD + blockIdx.x] + before + rank_in_wave;   // selected nodes with a smaller index
+  const uint32_t total_sel = P->all ? A.n_nodes : P->total_sel;
+  A.new_index[i] = sel ? sel_before : total_sel + (i - sel_before);
 }
 
 __global__ __launch_bounds__(256) void k_treelet_remap(TreeletArgs A) {

@@ -54,7 +54,7 @@ struct rt_ctx {
   DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, tri_shade, inst_trav, light_rec;
-  DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w;   // k_treelet.hip.h
+  DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w, treelet_work;   // k_treelet.hip.h
   std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true;
   int wf_block = 0;              // threads per workgroup of the wavefront trace kernels (0 = default; MI355RT_WF_BLOCK)
@@ -308,8 +308,19 @@ int prepare_scene(rt_ctx* c) {
     T.n_roots = (uint32_t)c->blas_roots.size();
     T.k_max = (uint32_t)(c->lds_per_cu / 32);
     const dim3 grid((c->n_nodes + 255) / 256);
+    const uint32_t n_blocks = (c->n_nodes + 1023u) / 1024u;
+    if ((r = ensure_buffer(c, c->treelet_work, ((size_t)RT_TREELET_WORK_HEAD + n_blocks) * 4, true)) < 0) return r;
+    uint32_t* work = (uint32_t*)c->treelet_work.ptr;
+    HIP_TRY(c, hipMemsetAsync(work, 0, (size_t)RT_TREELET_WORK_HEAD * 4, c->stream));
+    const dim3 hgrid(std::min<uint32_t>((c->n_nodes + 255) / 256, 256u));
     hipLaunchKernelGGL(rtk::k_treelet_weight, grid, dim3(256), 0, c->stream, T);
-    hipLaunchKernelGGL(rtk::k_treelet_order, dim3(1), dim3(1024), 0, c->stream, T);
+    hipLaunchKernelGGL(rtk::k_treelet_hist<0>, hgrid, dim3(256), 0, c->stream, T, work);
+    hipLaunchKernelGGL(rtk::k_treelet_pick<0>, dim3(1), dim3(256), 0, c->stream, T, work);
+    hipLaunchKernelGGL(rtk::k_treelet_hist<1>, hgrid, dim3(256), 0, c->stream, T, work);
+    hipLaunchKernelGGL(rtk::k_treelet_pick<1>, dim3(1), dim3(256), 0, c->stream, T, work);
+    hipLaunchKernelGGL(rtk::k_treelet_count, dim3(n_blocks), dim3(1024), 0, c->stream, T, work);
+    hipLaunchKernelGGL(rtk::k_treelet_blockscan, dim3(1), dim3(1024), 0, c->stream, work, n_blocks);
+    hipLaunchKernelGGL(rtk::k_treelet_number, dim3(n_blocks), dim3(1024), 0, c->stream, T, (const uint32_t*)work);
     hipLaunchKernelGGL(rtk::k_treelet_remap, grid, dim3(256), 0, c->stream, T);
     hipLaunchKernelGGL(rtk::k_treelet_inst_roots, dim3((c->n_instances + 255) / 256), dim3(256), 0, c->stream,
                        (const float4*)c->instances.ptr, (const uint32_t*)c->node_newidx.ptr, (uint32_t*)c->inst_root.ptr,
@@ -456,7 +467,7 @@ void rt_destroy(rt_ctx* c) {
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
                          &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
-                         &c->inst_root, &c->root_w};
+                         &c->inst_root, &c->root_w, &c->treelet_work};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -1375,6 +1386,18 @@ int rt_set_kernel_timing(rt_ctx* c, int enabled) {
   if (!c) return RT_ERR_INVALID;
   c->timing = enabled != 0;
   return RT_OK;
+}
+int rt_debug_read_traversal_nodes(rt_ctx* c, float* tnodes_out, uint32_t* new_index_out, uint32_t* inst_root_out, uint32_t cap_nodes) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = prepare_scene(c);
+  if (r < 0) return r;
+  if (cap_nodes < c->n_nodes || !c->tnodes.ptr) return fail(c, RT_ERR_INVALID, "rt_debug_read_traversal_nodes: no nodes or buffer too small");
+  if (tnodes_out) HIP_TRY(c, hipMemcpyAsync(tnodes_out, c->tnodes.ptr, (size_t)c->n_nodes * 32, hipMemcpyDeviceToHost, c->stream));
+  if (new_index_out) HIP_TRY(c, hipMemcpyAsync(new_index_out, c->node_newidx.ptr, (size_t)c->n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+  if (inst_root_out) HIP_TRY(c, hipMemcpyAsync(inst_root_out, c->inst_root.ptr, (size_t)c->n_instances * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return (int)c->n_nodes;
 }
 int rt_debug_trace_sections(rt_ctx* c, uint64_t* out16, int reset) {
   if (!c || !out16) return RT_ERR_INVALID;
