@@ -198,6 +198,9 @@ int rt_debug_read_traversal_nodes(rt_ctx* ctx, float* tnodes_out, uint32_t* new_
  * {retire / pull, node step, triangle flush}, 3..5 how often each did work, 6 waves, 7 loop trips.  Returns 1 in the
  * diagnostic build, 0 in the product build (where no stamp executes and the array stays zero). */
 int rt_debug_trace_sections(rt_ctx* ctx, uint64_t* out16, int reset);
+/* Diagnostic build (-DRT_PT_STAMPS) only: the same for k_pathtrace_persistent: out8[0..4] = cycles in {regenerate + start,
+ * shade, shadow traversal, extension traversal + surface frame, finish}, [5] trips, [6] waves. */
+int rt_debug_pt_sections(rt_ctx* ctx, uint64_t* out8, int reset);
 /* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
  *   3 = auto (default): wavefront form when the scene's records do not fit LDS, SPP == 1 and the dispatch carries
  *       >= 4 frames (rt_compute_batch); the persistent kernel otherwise

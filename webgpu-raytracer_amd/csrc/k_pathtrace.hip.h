@@ -375,6 +375,10 @@ __host__ __device__ inline size_t scene_lds_slots(uint32_t n_nodes, uint32_t n_t
 // delta(memtime) / delta(memrealtime) x 100 MHz.  In the product build no stamp executes.
 #define RT_CLOCK_STAMP_SLOTS 4096
 __device__ unsigned long long g_clock_stamps[2 * RT_CLOCK_STAMP_SLOTS];
+// Diagnostic build only (-DRT_PT_STAMPS, tools/pt_sections.py): s_memtime cycles the persistent kernel's waves spend in
+// the five sections of a trip (regenerate + start a sample, shade, shadow traversal, extension traversal + surface frame,
+// finish), summed over all waves; [5] = trips, [6] = waves.
+__device__ unsigned long long g_pt_sections[8];
 
 // Occupancy: the LDS-resident form is VALU-issue bound (3, 4, 5 waves/SIMD within 2 %), the global-memory form
 // is latency bound and gains ~11 % from 6 waves/SIMD even with the spills that costs (measured on MI355X).
@@ -511,7 +515,13 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   p.ro = p.rd = p.throughput = p.radiance = p.col = p.normal = p.geom_n = p.albedo = rt3_splat(0.0f);
   p.tex_uv = rt2_make(0.0f, 0.0f);
 
+#ifdef RT_PT_STAMPS
+  unsigned long long pt_cyc[5] = {0, 0, 0, 0, 0}, pt_trips = 0;
+#endif
   for (;;) {
+#ifdef RT_PT_STAMPS
+    const unsigned long long ps0 = __builtin_amdgcn_s_memtime();
+#endif
     // ------------------------------------------------------------ regenerate
     // (a) wave-wide: every lane without a pixel takes the next unassigned one of the wave's tile.
     //     All lanes execute this loop (busy lanes with need = false) so that the wave-uniform cursor
@@ -592,6 +602,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
     const bool running = alive;
     bool path_done = have_pixel && !alive;  // background sample ends immediately
 
+#ifdef RT_PT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long ps1 = __builtin_amdgcn_s_memtime();
+#endif
     // ------------------------------------------------------------ shade one bounce
     bool want_shadow = false, want_extend = false;
     bool nee_valid = false;
@@ -618,6 +632,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
 #ifdef RT_EXP_NOEXT
     if (want_extend) { want_extend = false; path_done = true; }  // timing experiment only
 #endif
+#ifdef RT_PT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long ps2 = __builtin_amdgcn_s_memtime();
+#endif
     // ------------------------------------------------------------ shadow rays (any hit)
     if (__ballot(want_shadow) != 0ull) {
       float t_;
@@ -631,6 +649,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       }
     }
 
+#ifdef RT_PT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long ps3 = __builtin_amdgcn_s_memtime();
+#endif
     // ------------------------------------------------------------ extension rays (closest hit)
     if (__ballot(want_extend) != 0ull) {
       float t_;
@@ -652,6 +674,10 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       }
     }
 
+#ifdef RT_PT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long ps4 = __builtin_amdgcn_s_memtime();
+#endif
     // ------------------------------------------------------------ sample / pixel finished
     if (path_done) {
       alive = false;
@@ -673,8 +699,23 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
         have_pixel = false;
       }
     }
+#ifdef RT_PT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    {
+      const unsigned long long ps5 = __builtin_amdgcn_s_memtime();
+      pt_cyc[0] += ps1 - ps0; pt_cyc[1] += ps2 - ps1; pt_cyc[2] += ps3 - ps2; pt_cyc[3] += ps4 - ps3; pt_cyc[4] += ps5 - ps4;
+      pt_trips++;
+    }
+#endif
     if (!work_left && __ballot(alive || have_pixel) == 0ull) break;
   }
+#ifdef RT_PT_STAMPS
+  if (lane == 0u) {
+    for (int k = 0; k < 5; k++) atomicAdd(&g_pt_sections[k], pt_cyc[k]);
+    atomicAdd(&g_pt_sections[5], pt_trips);
+    atomicAdd(&g_pt_sections[6], 1ull);
+  }
+#endif
 
 #ifdef RT_CLOCK_STAMP
   if (threadIdx.x == 0 && blockIdx.x < RT_CLOCK_STAMP_SLOTS) {

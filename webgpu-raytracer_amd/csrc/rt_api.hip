@@ -1414,6 +1414,21 @@ int rt_debug_trace_sections(rt_ctx* c, uint64_t* out16, int reset) {
   return 0;
 #endif
 }
+int rt_debug_pt_sections(rt_ctx* c, uint64_t* out8, int reset) {
+  if (!c || !out8) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtk::g_pt_sections), 64, 0, hipMemcpyDeviceToHost));
+  if (reset) {
+    uint64_t zero[8] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_pt_sections), zero, 64, 0, hipMemcpyHostToDevice));
+  }
+#ifdef RT_PT_STAMPS
+  return 1;
+#else
+  return 0;
+#endif
+}
 int rt_debug_clock_stamps(rt_ctx* c, uint64_t* out_pairs, uint32_t cap_pairs) {
   if (!c || !out_pairs) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
