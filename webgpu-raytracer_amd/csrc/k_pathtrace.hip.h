@@ -442,9 +442,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
   // per-wave triangle work queue at the start of LDS, staged scene after it
   WaveWork WW;
   {
-    char* wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
-    WW.rays = reinterpret_cast<f4*>(wbase);
-    WW.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+    wave_work_at(WW, reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE);
   }
   const uint32_t rec0 = (4 * RT_WORK_BYTES_PER_WAVE) / 16;   // first slot behind the wave queues
   TravMem M;

@@ -127,10 +127,16 @@ __device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& 
 // explicit successors of tnodes, which name the same nodes as `curr + 1` / `node_start + skip` do in the bridge array.
 // ANY = shadow ray (first accepted hit ends the ray), else closest hit.
 struct WaveWork {
-  f4* rays;         // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
-  uint32_t* items;  // up to 64*7: (owner lane << 26) | triangle id; overwritten by the result t (f32 bits)
+  f4* rays;                  // 64 x 2: {o.xyz, t_min} {d.xyz, bound at leaf entry}
+  uint32_t* items;           // up to 64*7: (owner lane << 26) | triangle id
+  unsigned long long* res;   // 64: per owner lane, the smallest (bits(t) << 32 | triangle id) among its accepted tests
 };
-#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4)
+#define RT_WORK_BYTES_PER_WAVE (64 * 32 + 64 * 7 * 4 + 64 * 8)
+__device__ __forceinline__ void wave_work_at(WaveWork& W, char* wbase) {
+  W.rays = reinterpret_cast<f4*>(wbase);
+  W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  W.res = reinterpret_cast<unsigned long long*>(wbase + 64 * 32 + 64 * 7 * 4);
+}
 #ifndef RT_STEPS_PER_TRIP
 #define RT_STEPS_PER_TRIP 4  // swept on MI355X (Cornell, ms per 32-frame launch): 1: 27.1, 2: 26.0, 3: 25.8, 4: 25.1, 6: 25.0, 8: 25.8, 12: 27.4
 #endif
@@ -233,6 +239,7 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
     rb.x = rt_opaque(s.r.d.x); rb.y = rt_opaque(s.r.d.y); rb.z = rt_opaque(s.r.d.z); rb.w = s.closest;
     W.rays[2 * lane] = ra;
     W.rays[2 * lane + 1] = rb;
+    W.res[lane] = ~0ull;
     const uint32_t tag = lane << 26;
 #pragma unroll
     for (uint32_t i = 0; i < 7u; i++)
@@ -260,33 +267,30 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
         g2 = ld_g(M.gtri, RT_TRI_STRIDE * (size_t)tri + 2);
       }
       float t;
-      bool ok = hit_tri_nb(g0, g1, g2, q, ra.w, rb.w, t);
-      W.items[j] = rt_f2u(ok ? t : -1.0f);
+      const bool ok = hit_tri_nb(g0, g1, g2, q, ra.w, rb.w, t);
+      // The reference's leaf loop (Raytracer.wgsl:474-482) accepts test i iff it passes and t_i < the running closest,
+      // so it ends with the smallest accepted t and, among equal ones, the first in leaf order: a minimum over
+      // (t, position), whatever the order of evaluation.  t > 0 here, so its bits order like the value; the triangle id
+      // grows with the position in the leaf.  ANY (shadow rays) needs only the first accepted position.
+      if (ok) atomicMin(&W.res[owner], ANY ? (unsigned long long)tri : (((unsigned long long)rt_f2u(t) << 32) | tri));
     }
   }
   __builtin_amdgcn_wave_barrier();
   if (s.waiting) {
-    // fold this lane's results in leaf order (strict t < closest: the first of equal hits wins)
-    bool stop = false;
-#pragma unroll
-    for (uint32_t i = 0; i < 7u; i++) {
-      if (i < cnt && !stop) {
-        if (COUNT) n_tris++;
-        const float t = rt_u2f(W.items[excl + i]);
-        if (t > 0.0f && t < s.closest) {
-          if (ANY) {
-            s.any = true;
-            stop = true;
-          } else {
-            s.closest = t;
-            s.best_tri = (int32_t)(first + i);
-            s.best_inst = (int32_t)s.cur_inst;
-          }
-        }
+    const unsigned long long best = W.res[lane];
+    const bool found = best != ~0ull;
+    if (COUNT) n_tris += (ANY && found) ? ((uint32_t)best - first + 1u) : cnt;   // the any-hit loop stops at its first hit
+    if (found) {
+      if (ANY) {
+        s.any = true;
+      } else {
+        s.closest = rt_u2f((uint32_t)(best >> 32));
+        s.best_tri = (int32_t)(uint32_t)best;
+        s.best_inst = (int32_t)s.cur_inst;
       }
     }
     s.waiting = false;
-    s.searching = !stop;
+    s.searching = !(ANY && found);
   }
   __builtin_amdgcn_wave_barrier();
   return true;

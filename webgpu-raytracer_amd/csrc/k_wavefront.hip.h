@@ -249,8 +249,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   extern __shared__ f4 s_scene[];
   WaveWork W;
   char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
-  W.rays = reinterpret_cast<f4*>(wbase);
-  W.items = reinterpret_cast<uint32_t*>(wbase + 64 * 32);
+  wave_work_at(W, wbase);
   const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
   TravMem M;
   if (LDS) {
