@@ -242,8 +242,18 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
     W.res[lane] = ~0ull;
     const uint32_t tag = lane << 26;
 #pragma unroll
-    for (uint32_t i = 0; i < 7u; i++)
+    for (uint32_t i = 0; i < 4u; i++)
       if (i < cnt) W.items[excl + i] = tag | (first + i);
+  }
+  // leaves of the reference's builder hold <= 4 triangles (blas.rs:99); only its fallback leaves hold 5-7: those three
+  // stores sit behind a wave-uniform test (count bit 2 set together with bit 0 or bit 1)
+  if ((b2 & (b0 | b1)) != 0ull) {
+    if (s.waiting) {
+      const uint32_t tag = lane << 26;
+#pragma unroll
+      for (uint32_t i = 4; i < 7u; i++)
+        if (i < cnt) W.items[excl + i] = tag | (first + i);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   const bool tri_lds = MODE == RT_TRAV_LDS || M.l_tri != RT_LDS_NONE;   // wave-uniform
