@@ -116,13 +116,14 @@ __device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& 
 //   * (lane, triangle) work items are compacted into LDS with a ballot/mbcnt prefix sum over the
 //     3-bit leaf counts, each owner also posts its instance-space ray;
 //   * the items are tested 64 at a time, one item per lane, whatever lane they came from — a leaf
-//     with 6 triangles no longer holds 63 other lanes hostage;
-//   * each owner then folds its own results in leaf order with the reference's strict `t < closest`
-//     rule and goes back to searching.
+//     with 6 triangles no longer holds 63 other lanes hostage — each against its owner's bound at leaf entry;
+//   * every accepted test does one LDS atomicMin of (bits(t) << 32 | triangle) into its owner's slot, the owner
+//     reads the winner and goes back to searching.
 // Equivalence with the reference's sequential leaf loop (Raytracer.wgsl:474-482): a test is accepted
 // there iff geometry passes, t > t_min and t < the running closest; the running closest never exceeds
-// the closest at leaf entry, so testing every triangle against the leaf-entry bound in parallel and
-// re-applying `t < running closest` in order during the fold makes exactly the same decisions.
+// the closest at leaf entry and only ever takes the value of an accepted t, so the loop ends with the SMALLEST
+// accepted t and, among equal ones, the one met first (strict <) — the minimum of (t, position in the leaf) over the
+// tests that pass against the leaf-entry bound, which is order-independent.  t > 0, so its bits order like its value.
 // Per lane the sequence of visited nodes, tested triangles and tie-breaks is the reference's: the walk follows the
 // explicit successors of tnodes, which name the same nodes as `curr + 1` / `node_start + skip` do in the bridge array.
 // ANY = shadow ray (first accepted hit ends the ray), else closest hit.
