@@ -1,0 +1,190 @@
+// gather_peak.hip — what one MI355X sustains on DEPENDENT, lane-divergent 16-byte gathers: the access pattern of a BVH
+// node step (every lane of a wave reads a different 32-byte record, and the next address depends on what came back).
+//
+// Each lane chases a random permutation through a table of 32-byte records: `loads` x global_load_dwordx4 per step from
+// one record (1 = 16 B, 2 = the 32-B node of k_traverse.hip.h, 4 = a 64-B pair of nodes), `lanes` lanes of every wave
+// active, `blocks` 256-thread workgroups per CU.  Table sizes walk the hierarchy: 16 KB (vector L1), 1 MB (L2), 4 MB
+// (the node array of the 263 k-triangle scene, per-XCD L2 = 4 MB), 64 MB (Infinity Cache).  Printed per run: lane-steps
+// per second chip-wide, and CU cycles per wave-level load instruction = clock x elapsed / (waves per CU x steps x
+// loads) — the figure to hold against "the vector L1 looks up one line per cycle".
+// A second table does the same walk with the records in LDS (ds_read_b128), the treelet's access pattern.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -o gather_peak tools/gather_peak.hip      run: ./gather_peak
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                     \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const f4 __attribute__((address_space(1))) * gptr;
+
+// record r = 2 x f4; .w of the first f4 holds the next record's index (as bits)
+template <int LOADS>
+__global__ __launch_bounds__(256) void k_chase(const f4* tab, uint32_t n_rec, uint32_t lanes, int iters, float* out,
+                                               unsigned long long* stamps) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u % n_rec;
+  float acc = 0.0f;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (lane < lanes) {
+    for (int it = 0; it < iters; it++) {
+      const size_t base = (LOADS == 4 ? 4 : 2) * (size_t)(LOADS == 4 ? (idx >> 1) : idx);
+      f4 a = ((gptr)tab)[base];
+      if (LOADS >= 2) {
+        f4 b = ((gptr)tab)[base + 1];
+        acc += b.x;
+      }
+      if (LOADS == 4) {
+        f4 c = ((gptr)tab)[base + 2], d = ((gptr)tab)[base + 3];
+        acc += c.y + d.z;
+      }
+      acc += a.x;
+      idx = __float_as_uint(a.w);
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = acc + (float)idx;
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = c1 - c0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
+template <int LOADS>
+__global__ __launch_bounds__(256) void k_chase_lds(const f4* tab, uint32_t n_rec, uint32_t lanes, int iters, float* out) {
+  extern __shared__ f4 lds[];
+  for (uint32_t i = threadIdx.x; i < 2u * n_rec; i += 256u) lds[i] = tab[i];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u % n_rec;
+  float acc = 0.0f;
+  if (lane < lanes) {
+    for (int it = 0; it < iters; it++) {
+      f4 a = lds[2u * idx];
+      if (LOADS >= 2) {
+        f4 b = lds[2u * idx + 1u];
+        acc += b.x;
+      }
+      acc += a.x;
+      idx = __float_as_uint(a.w);
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc + (float)idx;
+}
+
+int main() {
+  CHECK(hipSetDevice(0));
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("device: %s, %d CUs\n", prop.gcnArchName, cus);
+  const uint32_t sizes[] = {512u, 32768u, 131072u, 2097152u};   // records of 32 B: 16 KB, 1 MB, 4 MB, 64 MB
+  const uint32_t max_rec = 2097152u;
+  f4* tab;
+  float* out;
+  unsigned long long* stamps;
+  CHECK(hipMalloc(&tab, (size_t)max_rec * 32));
+  CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+  CHECK(hipMalloc(&stamps, (size_t)cus * 8 * 16));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<f4> host((size_t)max_rec * 2);
+  std::vector<unsigned long long> hs((size_t)cus * 8 * 2);
+  printf("%-8s %-6s %-6s %-7s %14s %16s %10s\n", "table", "loads", "lanes", "blk/CU", "Glane-steps/s", "CUcyc/wave-load", "clock GHz");
+  for (uint32_t n_rec : sizes) {
+    // one random cycle through all records (Sattolo), so every chain keeps wandering over the whole table
+    std::vector<uint32_t> perm(n_rec);
+    for (uint32_t i = 0; i < n_rec; i++) perm[i] = i;
+    uint64_t s = 88172645463325252ull;
+    for (uint32_t i = n_rec - 1; i > 0; i--) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      uint32_t j = (uint32_t)(s % i);
+      std::swap(perm[i], perm[j]);
+    }
+    for (uint32_t i = 0; i < n_rec; i++) {
+      f4 a = {1e-9f, 0.f, 0.f, 0.f}, b = {1e-9f, 0.f, 0.f, 0.f};
+      uint32_t nx = perm[i];
+      { float fw; memcpy(&fw, &nx, 4); a.w = fw; }
+      host[2 * (size_t)i] = a;
+      host[2 * (size_t)i + 1] = b;
+    }
+    CHECK(hipMemcpy(tab, host.data(), (size_t)n_rec * 32, hipMemcpyHostToDevice));
+    for (int loads : {1, 2, 4}) {
+      for (uint32_t lanes : {64u, 40u, 16u}) {
+        for (int blocks : {2, 4, 6, 8}) {
+          if ((lanes != 40u && blocks != 6) || (loads == 4 && lanes != 40u)) continue;
+          const int iters = n_rec <= 512u ? 20000 : 4000;
+          const int grid = cus * blocks;
+          float ms = 0.f;
+          for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            if (loads == 1) hipLaunchKernelGGL(k_chase<1>, dim3(grid), dim3(256), 0, 0, tab, n_rec, lanes, iters, out, stamps);
+            if (loads == 2) hipLaunchKernelGGL(k_chase<2>, dim3(grid), dim3(256), 0, 0, tab, n_rec, lanes, iters, out, stamps);
+            if (loads == 4) hipLaunchKernelGGL(k_chase<4>, dim3(grid), dim3(256), 0, 0, tab, n_rec, lanes, iters, out, stamps);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+          }
+          CHECK(hipMemcpy(hs.data(), stamps, (size_t)grid * 16, hipMemcpyDeviceToHost));
+          double clk = 0;
+          for (int b = 0; b < grid; b++) clk += (double)hs[2 * b] / (double)hs[2 * b + 1] * 0.1;
+          clk /= grid;
+          const double steps = (double)grid * 4 * lanes * iters;
+          const double cyc = clk * 1e9 * ms * 1e-3 / ((double)blocks * 4 * iters * loads);
+          printf("%-8s %-6d %-6u %-7d %14.1f %16.1f %10.2f\n",
+                 n_rec == 512u ? "16KB" : n_rec == 32768u ? "1MB" : n_rec == 131072u ? "4MB" : "64MB", loads, lanes, blocks,
+                 steps / (ms * 1e-3) * 1e-9, cyc, clk);
+          fflush(stdout);
+        }
+      }
+    }
+  }
+  // the same walk with the table in LDS (treelet pattern): 2048 records = 64 KB per workgroup, 2 workgroups per CU
+  {
+    const uint32_t n_rec = 2048u;
+    CHECK(hipFuncSetAttribute((const void*)k_chase_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CHECK(hipFuncSetAttribute((const void*)k_chase_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CHECK(hipMemcpy(tab, host.data(), 0, hipMemcpyHostToDevice));
+    std::vector<uint32_t> perm(n_rec);
+    for (uint32_t i = 0; i < n_rec; i++) perm[i] = (i * 1103515245u + 12345u) % n_rec;
+    for (uint32_t i = 0; i < n_rec; i++) {
+      f4 a = {1e-9f, 0.f, 0.f, 0.f};
+      uint32_t nx = (i * 677u + 13u) % n_rec;   // 677 is odd: a permutation of 0..2047 with long cycles
+      { float fw; memcpy(&fw, &nx, 4); a.w = fw; }
+      host[2 * (size_t)i] = a;
+      host[2 * (size_t)i + 1] = a;
+    }
+    CHECK(hipMemcpy(tab, host.data(), (size_t)n_rec * 32, hipMemcpyHostToDevice));
+    for (int loads : {1, 2}) {
+      for (uint32_t lanes : {64u, 40u}) {
+        const int iters = 20000, blocks = 2, grid = cus * blocks;
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; rep++) {
+          CHECK(hipEventRecord(e0));
+          if (loads == 1) hipLaunchKernelGGL(k_chase_lds<1>, dim3(grid), dim3(256), 65536, 0, tab, n_rec, lanes, iters, out);
+          if (loads == 2) hipLaunchKernelGGL(k_chase_lds<2>, dim3(grid), dim3(256), 65536, 0, tab, n_rec, lanes, iters, out);
+          CHECK(hipEventRecord(e1));
+          CHECK(hipEventSynchronize(e1));
+          CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        const double steps = (double)grid * 4 * lanes * iters;
+        printf("%-8s %-6d %-6u %-7d %14.1f %16.1f (at 2.4 GHz)\n", "LDS64KB", loads, lanes, blocks, steps / (ms * 1e-3) * 1e-9,
+               2.4e9 * ms * 1e-3 / ((double)blocks * 4 * iters * loads));
+      }
+    }
+  }
+  return 0;
+}

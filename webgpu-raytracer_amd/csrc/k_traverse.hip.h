@@ -153,6 +153,7 @@ struct Trav {  // one ray's traversal state
   int32_t best_tri, best_inst;
   uint32_t curr, tlas_next, cur_inst, leaf;
   bool searching, waiting, in_blas, any;
+  bool entering;             // mixed mode: hit a TLAS leaf, instance entry pending (still `searching`)
 };
 
 __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_max) {
@@ -169,14 +170,13 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
   s.waiting = false;
   s.in_blas = false;
   s.any = false;
+  s.entering = false;
 }
 
-// one node step for every searching lane; select-based, two branches only
-template <bool COUNT, int MODE>
-__device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
-  // ---- the walk ran off its array (rare): leave the instance (back to the world-space ray and the TLAS cursor), or
-  // finish.  Written as selects behind a wave-uniform test: as a per-lane branch that recomputes the ray, the twelve
-  // registers of the ray were copied out and back on EVERY trip to merge the two paths.
+// the walk ran off its array (rare): leave the instance (back to the world-space ray and the TLAS cursor), or finish.
+// Written as selects behind a wave-uniform test: as a per-lane branch that recomputes the ray, the twelve registers of
+// the ray were copied out and back on EVERY trip to merge the two paths.
+__device__ __forceinline__ void trav_leave(Trav& s) {
   const bool at_end = s.searching && s.curr == RT_NODE_END;
   if (__ballot(at_end) != 0ull) {
     const bool leave = at_end && s.in_blas && s.tlas_next != RT_NODE_END;
@@ -190,28 +190,126 @@ __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav&
     s.in_blas = s.in_blas && !leave;
     s.searching = s.searching && (!at_end || leave);
   }
-  if (s.searching) {
-    f4 lo, hi;
-    trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
-    if (COUNT) n_nodes++;
-    const bool hit = hit_box4(lo, hi, s.r, RT_T_MIN, s.closest);
-    const uint32_t data = rt_f2u(hi.w);
-    const bool inner = (data & RT_NODE_INNER) != 0u;
-    const bool leafhit = hit && !inner;
-    uint32_t next = (hit && inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
-    const bool got_leaf = leafhit && s.in_blas;
-    if (leafhit && !s.in_blas) {  // TLAS leaf: enter the instance
-      s.cur_inst = data >> 3;
+}
+
+// instance entry of the lanes that hit a TLAS leaf (deferred form): object-space ray, BLAS root
+template <int MODE>
+__device__ __forceinline__ void trav_enter(const TravMem& M, const f4* lds, Trav& s) {
+  if (s.entering) {
+    uint32_t root;
+    s.r = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
+    s.curr = root;
+    s.in_blas = true;
+    s.entering = false;
+  }
+}
+
+// what a lane does with the node record it fetched (Raytracer.wgsl:462-473, 498-518): slab test against the current
+// bound, successor, leaf bookkeeping.  DEFER: a TLAS-leaf hit only marks the lane as `entering` (trav_enter does the
+// transform later, for many lanes at once); otherwise the instance is entered on the spot.
+template <bool COUNT, int MODE, bool DEFER>
+__device__ __forceinline__ void trav_node(const TravMem& M, const f4* lds, Trav& s, f4 lo, f4 hi, uint32_t& n_nodes) {
+  if (COUNT) n_nodes++;
+  const bool hit = hit_box4(lo, hi, s.r, RT_T_MIN, s.closest);
+  const uint32_t data = rt_f2u(hi.w);
+  const bool inner = (data & RT_NODE_INNER) != 0u;
+  const bool leafhit = hit && !inner;
+  uint32_t next = (hit && inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
+  const bool got_leaf = leafhit && s.in_blas;
+  if (leafhit && !s.in_blas) {  // TLAS leaf: enter the instance
+    s.cur_inst = data >> 3;
+    s.tlas_next = next;
+    if (DEFER) {
+      s.entering = true;
+      next = 0u;   // any node but RT_NODE_END: trav_leave must not take the lane for one that ran off its array
+    } else {
       uint32_t root;
       s.r = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
-      s.tlas_next = next;
       next = root;
       s.in_blas = true;
     }
-    s.leaf = got_leaf ? data : s.leaf;
-    s.waiting = got_leaf;
-    s.searching = !got_leaf;
-    s.curr = next;
+  }
+  s.leaf = got_leaf ? data : s.leaf;
+  s.waiting = got_leaf;
+  s.searching = !got_leaf;
+  s.curr = next;
+}
+
+// one node step for every searching lane; select-based, two branches only
+template <bool COUNT, int MODE>
+__device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
+  trav_leave(s);
+  if (s.searching) {
+    f4 lo, hi;
+    trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
+    trav_node<COUNT, MODE, false>(M, lds, s, lo, hi, n_nodes);
+  }
+}
+
+// ---- mixed mode (part of the records in LDS, the rest behind the vector L1): phased trip.
+// Measured on MI355X (tools/gather_peak.hip): a wave-level global_load_dwordx4 with lane-divergent addresses costs the
+// CU's texture-address path 16 cycles + 0.35 per active lane whether it hits the L1 or not (30 at 40 lanes; a 32-byte
+// node is two of them), a divergent ds_read_b128 6-9 — and the trace kernels spend 70 CU cycles per wave node step.  A
+// step that lets every lane fetch "from wherever its node lives" therefore pays the full global instruction for the few
+// lanes that need it.  The phased trip makes global instructions rare and full:
+//   * the lanes whose node is global issue their two loads first;
+//   * while those are in flight, the lanes whose node is in LDS take up to RT_LDS_SUBSTEPS steps of their own (each of
+//     them has then either reached a global node, a leaf, an instance or its end);
+//   * the global lanes finish their step;
+//   * a lane that hit a TLAS leaf does not transform its ray on the spot (three more divergent loads for a handful of
+//     lanes when the instance rows are not LDS-resident): it waits as `entering` until RT_ENTER_BATCH lanes do, or
+//     nobody else can step.
+// Per lane the sequence of nodes, tests and bounds is untouched — only WHEN a lane takes its next step changes.
+#ifndef RT_LDS_SUBSTEPS
+#define RT_LDS_SUBSTEPS 4
+#endif
+#ifndef RT_ENTER_BATCH
+#define RT_ENTER_BATCH 16u
+#endif
+template <bool COUNT, int ROUNDS>
+__device__ __forceinline__ void trav_trip_mixed(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
+  constexpr int MODE = RT_TRAV_MIXED;
+  const bool inst_lds = M.l_inst != RT_LDS_NONE;   // wave-uniform
+#pragma unroll
+  for (int k = 0; k < ROUNDS; k++) {
+    trav_leave(s);
+    {
+      const unsigned long long em = __ballot(s.entering);
+      if (em != 0ull && (inst_lds || (uint32_t)__builtin_popcountll(em) >= RT_ENTER_BATCH ||
+                         __ballot(s.searching && !s.entering) == 0ull))
+        trav_enter<MODE>(M, lds, s);
+    }
+    const bool g = s.searching && !s.entering && s.curr >= M.k_lds;
+    f4 glo, ghi;
+    if (g) {
+      glo = ld_g(M.gnodes, 2 * (size_t)s.curr);
+      ghi = ld_g(M.gnodes, 2 * (size_t)s.curr + 1);
+    }
+    if (M.k_lds != 0u) {
+#pragma unroll 1
+      for (int j = 0; j < RT_LDS_SUBSTEPS; j++) {
+        if (inst_lds && __ballot(s.entering) != 0ull) trav_enter<MODE>(M, lds, s);
+        const bool l = s.searching && !s.entering && !g && s.curr < M.k_lds;   // RT_NODE_END is never < k_lds
+        if (__ballot(l) == 0ull) break;
+        if (l) {
+          const f4 lo = ld_l(lds, M.l_nodes + 2u * s.curr), hi = ld_l(lds, M.l_nodes + 2u * s.curr + 1u);
+          trav_node<COUNT, MODE, true>(M, lds, s, lo, hi, n_nodes);
+        }
+        trav_leave(s);   // a lane that ran off its array; the lanes with a load in flight are not at an end
+      }
+    }
+    if (g) trav_node<COUNT, MODE, true>(M, lds, s, glo, ghi, n_nodes);
+  }
+}
+
+// the node steps between two looks at the queues
+template <bool COUNT, int MODE, int STEPS>
+__device__ __forceinline__ void trav_trip(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
+  if (MODE == RT_TRAV_LDS) {
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) trav_step<COUNT, MODE>(M, lds, s, n_nodes);
+  } else {
+    trav_trip_mixed<COUNT, STEPS>(M, lds, s, n_nodes);
   }
 }
 
@@ -317,8 +415,7 @@ __device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const 
   for (;;) {
     // RT_STEPS_PER_TRIP node steps between two looks at the triangle queue: the look (ballots, population counts, the
     // branch) costs a third of a trip; a lane that reaches a leaf in an earlier step simply sits out the later ones
-#pragma unroll
-    for (int k = 0; k < RT_STEPS_PER_TRIP; k++) trav_step<COUNT, MODE>(M, lds, s, n_nodes);
+    trav_trip<COUNT, MODE, RT_STEPS_PER_TRIP>(M, lds, s, n_nodes);
     if (!trav_flush<ANY, COUNT, MODE>(M, lds, W, s, n_tris)) break;
   }
   out_t = s.closest;

@@ -344,8 +344,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     st_cyc[0] += st1 - st0;
     if (__ballot(s.searching) != 0ull) st_cnt[1]++;
 #endif
-#pragma unroll
-    for (int k = 0; k < RT_WF_STEPS_PER_TRIP; k++) trav_step<DETAIL, MODE>(M, s_scene, s, n_nodes);
+    trav_trip<DETAIL, MODE, RT_WF_STEPS_PER_TRIP>(M, s_scene, s, n_nodes);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();

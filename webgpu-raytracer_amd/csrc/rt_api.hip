@@ -882,8 +882,8 @@ int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32
 
 int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
 
-// What one workgroup stages in LDS behind its wave queues, given `budget` bytes of LDS per workgroup: as many of the
-// first (most visited) tnodes as fit, then the triangle records and the instance rows + BLAS roots if they fit whole.
+// What one workgroup stages in LDS behind its wave queues, given `budget` bytes of LDS per workgroup: the tnodes, the
+// triangle records and the instance rows + BLAS roots, each if it fits whole.
 // *dyn_bytes = dynamic LDS size of the launch.
 static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes, size_t* dyn_bytes) {
   rtk::LdsPlan P;
@@ -891,8 +891,10 @@ static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes,
   budget &= ~(size_t)2047;   // LDS is allocated in granules: leave room so that the intended number of workgroups fits a CU
   size_t avail = budget > queue_bytes ? budget - queue_bytes : 0;
   avail &= ~(size_t)15;
-  size_t k = std::min<size_t>(c->n_nodes, avail / 32);
-  if (c->treelet_cap >= 0) k = std::min<size_t>(k, (size_t)c->treelet_cap);   // MI355RT_TREELET_MAX (experiments)
+  // Nodes: all of them or none.  A partial treelet (the most visited nodes in LDS, the rest behind the L1) was measured
+  // at 350 ... 3 200 nodes and never paid; MI355RT_TREELET_MAX = n stages min(n, what fits) for sweeps.
+  size_t k = (size_t)c->n_nodes * 32 <= avail ? c->n_nodes : 0;
+  if (c->treelet_cap >= 0) k = std::min<size_t>(std::min<size_t>(c->n_nodes, avail / 32), (size_t)c->treelet_cap);
   P.k_nodes = (uint32_t)k;
   avail -= k * 32;
   const size_t tri_bytes = (size_t)c->n_tris * 16 * RT_TRI_STRIDE;
