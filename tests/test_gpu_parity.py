@@ -384,6 +384,30 @@ def test_wavefront_form_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, 
     pu.assert_parity(gpu_renderer, cpu, check_output=True, check_counters=False)
 
 
+@pytest.mark.parametrize("scene,treelet,variant", [
+    ("sponza_like", 64, 2), ("sponza_like", 100000, 2), ("instanced1000", 300, 2), ("instanced1000", 100000, 1),
+    ("glass_blob", 1000, 2),
+])
+def test_partial_node_staging_parity(W, oracle_lib, monkeypatch, scene, treelet, variant):
+    """MI355RT_TREELET_MAX = n stages the first n traversal nodes in LDS beside the L1-served rest (not the default:
+    nodes are staged all or not at all).  That path interleaves LDS-resident and global node steps and defers instance
+    entries; per ray it must still do exactly what the oracle does, counters included."""
+    monkeypatch.setenv("MI355RT_TREELET_MAX", str(treelet))
+    b = pu.bridge_for(W, scene)
+    w, h, depth, frames = 64, 40, 8, (1, 2, 3, 4)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
+    r = W.WebGPURenderer(0)
+    r.setKernelVariant(variant)
+    r.buildPipeline(depth, 1)
+    W.upload_scene(r, b, w, h)
+    r.setCounting(True)
+    r.resetCounters()
+    r.computeBatch(list(frames))
+    r.sync()
+    pu.assert_parity(r, cpu, check_output=False)
+
+
 @pytest.mark.parametrize("variant", [2, 3])
 def test_wavefront_form_with_stripes(W, gpu_renderer, variant):
     """Sharded render of a scene that does not fit LDS (auto = wavefront form): the ranks' stripes sum to the

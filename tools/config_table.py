@@ -35,7 +35,8 @@ for name, scene, w, h, frames, depth, div in CONFIGS:
     g.buildPipeline(depth, 1)
     W.upload_scene(g, b, w, h)
     fr = list(range(1, frames + 1))
-    B = 32 if w * h <= 1920 * 1080 else 8      # frames per batched dispatch (one G-buffer per frame in flight)
+    B = 32      # frames per batched dispatch (the recorder's cap is 50; at 4K the path state + queues + G-buffers of 32 frames
+                # are 63 GB of the 288: a depth-16 batch is 49 launches, and their drain tails are paid per batch)
     g.computeBatch(fr[:B])                     # first-use allocations and module load stay out of the timed image
     g.sync()
     g.resetAccumulation()
