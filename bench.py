@@ -11,7 +11,7 @@ N > 1    : `python bench.py --gpus N` starts its own N ranks (one process per GP
            The image is split into interleaved 8-row stripes across ranks (strong scaling of one image), one RCCL
            sum-reduce of the float4 accumulation buffer to rank 0 per image.
 Extra    : "roofline" for the dominant kernel (k_pathtrace_persistent; launch time from HIP events inside the C
-           library, on the stream the kernel runs on), "configs" (BASELINE configs 3 and 4, timed the same way,
+           library, on the stream the kernel runs on), "configs" (BASELINE configs 2-5, timed the same way,
            with the roofline of their dominant kernel k_wf_trace) and "cpu_baseline" (the CPU oracle timed on a
            bounded row-interleaved sample of the same workload, rank 0 at N = 1 only).
 Fields that cannot be measured from inside this process (PMC counters) are read from profiles/ and every such field
@@ -36,9 +36,13 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip
 L2_PEAK_GBS = 34500.0        # aggregate L2 bandwidth, 8 XCDs (MI355X_MICROARCH.md §L2)
 # f32 VALU: 157.3 TFLOP/s spec = 256 CUs x 4 SIMDs x 32 lanes/clk x 2 flop (FMA) x 2.4 GHz, i.e. 78.6 T lane-instructions/s
 VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
-EXTRA_CONFIGS = [  # (BASELINE.json config, scene, frames, depth, images timed)
-    ("3 instanced diamond x1000", "instanced1000", 64, 8, 3),
-    ("4 sponza-like 263k tris, 8 textures", "sponza_like", 64, 8, 3),
+DIAMOND_OBJ = ("v 0 1 0\nv 1 0 0\nv 0 0 1\nv -1 0 0\nv 0 0 -1\nv 0 -1 0\n"
+               "f 1 3 2\nf 1 2 5\nf 1 5 4\nf 1 4 3\nf 6 2 3\nf 6 5 2\nf 6 4 5\nf 6 3 4\n")   # the octahedron of public/diamond.obj
+EXTRA_CONFIGS = [  # (BASELINE.json config, scene, frames, depth, images timed, width, height)
+    ("2 viewer + diamond.obj", "viewer_diamond", 16, 8, 20, 1280, 720),
+    ("3 instanced diamond x1000", "instanced1000", 64, 8, 3, 1920, 1080),
+    ("4 sponza-like 263k tris, 8 textures", "sponza_like", 64, 8, 3, 1920, 1080),
+    ("5 glass blob 205k tris", "glass_blob", 256, 16, 1, 3840, 2160),
 ]
 
 
@@ -48,7 +52,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs 3 / 4 lines")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the lines of BASELINE configs 2-5")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
     return ap.parse_args()
@@ -222,13 +226,16 @@ def main():
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
         return float(tmax.item()), float(rsum.item())
 
-    def run_workload(scene, frames, depth, steps, warmup, batch):
+    def run_workload(scene, frames, depth, steps, warmup, batch, width=WIDTH, height=HEIGHT):
         """Time `steps` images of one scene on all ranks; returns the renderer, the sharding and the measurements."""
         bridge = pkg.WorldBridge()
-        bridge.loadScene(scene)
+        if scene == "viewer_diamond":
+            bridge.loadScene("viewer", DIAMOND_OBJ)
+        else:
+            bridge.loadScene(scene)
         r = pkg.WebGPURenderer(local_rank)
         r.buildPipeline(depth, 1)
-        pkg.upload_scene(r, bridge, WIDTH, HEIGHT)
+        pkg.upload_scene(r, bridge, width, height)
         shard = rtdist.ShardedImage(r, rank, world, device=device, collective_on_device=(backend == "nccl"),
                                     force_collective=force_dist)
 
@@ -268,9 +275,11 @@ def main():
     head = run_workload(SCENE, frames, DEPTH, args.steps, args.warmup, args.batch)
     extra = []
     if not args.no_extra_configs:
-        for name, scene, nframes, depth, images in EXTRA_CONFIGS:
-            m = run_workload(scene, list(range(1, nframes + 1)), depth, images, 1, args.batch)
-            extra.append((name, scene, nframes, depth, m))
+        for name, scene, nframes, depth, images, cw, ch in EXTRA_CONFIGS:
+            m = run_workload(scene, list(range(1, nframes + 1)), depth, images, 1, args.batch, cw, ch)
+            m["renderer"].destroy()      # the 4K batch holds 63 GB of path state, queues and G-buffers
+            m["renderer"] = None
+            extra.append((name, scene, nframes, depth, m, cw, ch))
 
     if rank == 0:
         ref = pmc_reference()
@@ -333,12 +342,12 @@ def main():
             "roofline": roof,
         }
         cfgs = []
-        for name, scene, nframes, depth, m in extra:
+        for name, scene, nframes, depth, m, cw, ch in extra:
             kt, kc = m["ktimes"], m["kc"]
             trace_ms = kt["wf_trace_shadow"]["ms"] + kt["wf_trace_ext"]["ms"]
             trace_bytes = 32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"]    # per image (detailed pass = one image)
             per_image_trace_ms = trace_ms / m["steps"]
-            entry = {"config": name, "workload": "%s 1920x1080, %d frames x depth %d, batches of %d" % (scene, nframes, depth, args.batch),
+            entry = {"config": name, "workload": "%s %dx%d, %d frames x depth %d, batches of %d" % (scene, cw, ch, nframes, depth, min(args.batch, nframes)),
                      "ms_per_image": round(m["elapsed"] / m["steps"] * 1e3, 2),
                      "Mrays_s": round(m["rays"] / m["elapsed"] / 1e6, 1), "images": m["steps"],
                      "kernel_ms_per_image": {k: round(v["ms"] / m["steps"], 3) for k, v in kt.items() if v["launches"]}}
