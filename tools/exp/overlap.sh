@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02m
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "wavefront or forms or band or staging" > gpurun_out/r02m/overlap_parity.log 2>&1 || { tail -30 gpurun_out/r02m/overlap_parity.log; exit 1; }
+tail -2 gpurun_out/r02m/overlap_parity.log
+for o in 0 1; do
+echo "== MI355RT_WF_OVERLAP=$o"
+for s in sponza_like instanced1000; do MI355RT_WF_OVERLAP=$o timeout -k 10 120 python tools/prof_frames.py $s 1920 1080 64 8 3 0 1 32 2>&1 | tail -3 | head -2; done
+MI355RT_WF_OVERLAP=$o timeout -k 10 200 python tools/prof_frames.py glass_blob 3840 2160 32 16 3 0 1 32 2>&1 | tail -3 | head -2
+done

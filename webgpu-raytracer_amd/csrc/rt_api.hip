@@ -45,6 +45,12 @@ struct rt_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // wavefront form: the any-hit trace of a depth runs on `side_stream` beside the closest-hit trace on `stream` (the two
+  // read the same shade output and write different result arrays), so the drain tail of one — a few long rays stepping
+  // alone — is filled by the other.  MI355RT_WF_OVERLAP=0 puts both on `stream` again.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  bool wf_overlap = true;
   std::string error;
 
   // scene buffers (raw bridge layout)
@@ -424,6 +430,17 @@ rt_ctx* rt_create(int device_ordinal) {
     return nullptr;
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) {
+    g_create_error = "hipStreamCreate / hipEventCreate (side stream) failed";
+    if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+  }
+  if (const char* e = getenv("MI355RT_WF_OVERLAP")) c->wf_overlap = atoi(e) != 0;
   if (const char* e = getenv("MI355RT_WF_BLOCK")) {
     const int b = atoi(e);
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
@@ -477,6 +494,9 @@ void rt_destroy(rt_ctx* c) {
   if (c->slot_ring) (void)hipHostFree(c->slot_ring);
   for (int k = 0; k < rt_ctx::kSlotRing; k++)
     if (c->slot_ring_ev[k]) (void)hipEventDestroy(c->slot_ring_ev[k]);
+  if (c->side_join) (void)hipEventDestroy(c->side_join);
+  if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1014,10 +1034,18 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       rt_scene_uniforms Ua = c->uniforms;
       void* args[] = {&Sa, &Fa, &Ua, &Q, &depth, &nn, &nt, &ni, &plan};
       EventPair* evt = next_events(c, k == 0 ? RT_TIMER_WF_TRACE_SHADOW : RT_TIMER_WF_TRACE_EXT);
-      if (evt) HIP_TRY(c, hipEventRecord(evt->a, c->stream));
-      HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(block), args, dyn, c->stream));
-      if (evt) HIP_TRY(c, hipEventRecord(evt->b, c->stream));
+      hipStream_t st = c->stream;
+      if (k == 0 && c->wf_overlap) {   // any-hit trace: fork to the side stream behind this depth's shade kernel
+        st = c->side_stream;
+        HIP_TRY(c, hipEventRecord(c->side_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->side_fork, 0));
+      }
+      if (evt) HIP_TRY(c, hipEventRecord(evt->a, st));
+      HIP_TRY(c, hipLaunchKernel(trace_fn[k], dim3(blocks), dim3(block), args, dyn, st));
+      if (evt) HIP_TRY(c, hipEventRecord(evt->b, st));
+      if (k == 0 && c->wf_overlap) HIP_TRY(c, hipEventRecord(c->side_join, st));
     }
+    if (c->wf_overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));   // the next shade needs both results
   }
   {
     // one more shade pass: the paths that ended at the last depth but were waiting for their shadow ray are finished
