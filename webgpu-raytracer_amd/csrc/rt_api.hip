@@ -952,7 +952,11 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   int r = ensure_buffer(c, c->wf_state, items * sizeof(WfPath), false);
   if (r < 0) return r;
   // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
-  const size_t qcap = items + (size_t)5 * 1024 * 1024;
+  // shade kernels: persistent waves that loop over the items; every wave may leave one partly used chunk per queue
+  int shade_per_cu = 16;
+  if (const char* e = getenv("MI355RT_SHADE_BLOCKS_PER_CU")) shade_per_cu = std::max(1, std::min(4096, atoi(e)));
+  const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * (size_t)shade_per_cu);
+  const size_t qcap = items + (size_t)shade_blocks * 4 * 256 + 1024 * 1024;
   // per item: active[2] + shadow ids + ext ids + occlusion word (5 x 4 B) + shadow rays, extension rays (2 x 32 B) + hits (16 B)
   r = ensure_buffer(c, c->wf_queues, qcap * 100, false);
   if (r < 0) return r;
@@ -1007,7 +1011,6 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     c->wf_occ_block = block;
   }
   uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
-  const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * 16);
   EventPair* ev = next_events(c, RT_TIMER_PATHTRACE);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   for (uint32_t depth = 0; depth < depths; depth++) {
