@@ -26,6 +26,9 @@ if [ "$WHAT" = cornell ] || [ "$WHAT" = all ]; then
   python3 $R/tools/pmc_collect.py $OUT/pmc_cornell $OUT/r02_cornell_pmc.json > /dev/null
 fi
 if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
+  # per-kernel durations and counters: the two trace kernels of a depth one after the other (by default they share the GPU
+  # on two streams and their durations overlap)
+  export MI355RT_WF_OVERLAP=0
   for scene in sponza_like instanced1000; do
     rm -rf $OUT/pmc_$scene
     timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$scene -- python3 $R/tools/prof_workload.py $scene 64 8 32 1 > $OUT/trace_$scene.log 2>&1
@@ -43,12 +46,14 @@ if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
   done
 fi
 if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
-  # config 5 (4K, depth 16): kernel trace of one 8-frame batch
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_glass -- python3 $R/tools/prof_workload.py glass_blob 8 16 8 1 3840 2160 > $OUT/trace_glass_blob.log 2>&1
+  # config 5 (4K, depth 16): kernel trace of one 32-frame batch
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_glass -- python3 $R/tools/prof_workload.py glass_blob 32 16 32 1 3840 2160 > $OUT/trace_glass_blob.log 2>&1
   cp $OUT/trace_glass/*/*_kernel_stats.csv $OUT/r02_glass_blob_kernel_stats.csv
   rm -rf $OUT/trace_glass
+  unset MI355RT_WF_OVERLAP
 fi
 timeout -k 10 120 $R/tools/bin/valu_peak > $OUT/r02_valu_peak.txt 2>&1
+timeout -k 10 300 $R/tools/bin/gather_peak > $OUT/r02_gather_peak.txt 2>&1
 timeout -k 10 200 python3 $R/tools/clock_check.py $OUT/r02_clock_check.json > $OUT/clock_check.log 2>&1
 python3 $R/tools/pmc_reference.py $OUT ${HEAD:-unknown} $OUT/pmc_reference.json > /dev/null
 ls $OUT
