@@ -9,11 +9,42 @@ DIAMOND_OBJ = ("v 0.0 1.0 0.0\nv 1.0 0.0 0.0\nv 0.0 0.0 1.0\nv -1.0 0.0 0.0\nv 0
 _bridges = {}
 
 
+def diamond_obj_subdivided(n=11):
+    """BASELINE.json words config 2 as a "~1k tris" diamond; public/diamond.obj is the 8-triangle octahedron.  Config 2b:
+    the same octahedron with every face cut into n x n congruent triangles (n = 11: 968 triangles, 486 vertices on the
+    flat faces — same shape, a deeper BLAS), as OBJ text for the `viewer` scene."""
+    base_v = [(0, 1, 0), (1, 0, 0), (0, 0, 1), (-1, 0, 0), (0, 0, -1), (0, -1, 0)]
+    base_f = [(1, 3, 2), (1, 2, 5), (1, 5, 4), (1, 4, 3), (6, 2, 3), (6, 5, 2), (6, 4, 5), (6, 3, 4)]
+    verts, index, faces = [], {}, []
+
+    def vid(p):
+        key = tuple(round(c * n) for c in p)          # barycentric lattice points are exact multiples of 1/n
+        if key not in index:
+            index[key] = len(verts) + 1
+            verts.append(tuple(k / n for k in key))
+        return index[key]
+
+    for fa, fb, fc in base_f:
+        a, b, c = (np.array(base_v[i - 1], dtype=np.float64) for i in (fa, fb, fc))
+        grid = {}
+        for i in range(n + 1):
+            for j in range(n + 1 - i):
+                grid[i, j] = vid(a + (b - a) * (i / n) + (c - a) * (j / n))
+        for i in range(n):
+            for j in range(n - i):
+                faces.append((grid[i, j], grid[i + 1, j], grid[i, j + 1]))
+                if j < n - i - 1:
+                    faces.append((grid[i + 1, j], grid[i + 1, j + 1], grid[i, j + 1]))
+    return "".join("v %.9g %.9g %.9g\n" % v for v in verts) + "".join("f %d %d %d\n" % f for f in faces)
+
+
 def bridge_for(pkg, scene):
     if scene not in _bridges:
         b = pkg.WorldBridge()
         if scene == "viewer_diamond":
             b.loadScene("viewer", DIAMOND_OBJ)
+        elif scene == "viewer_diamond_1k":
+            b.loadScene("viewer", diamond_obj_subdivided())
         else:
             b.loadScene(scene)
         _bridges[scene] = b

@@ -126,7 +126,7 @@ UNREACHABLE = {"special": 280, "mixed": 1920, "sponza_like": 83160, "glass_blob"
 # extent.y > extent.x, so a one-cell-high strip running along z has every centroid in ONE y-bin, cannot be split and
 # becomes a fallback leaf of 8-46 triangles whose count overflows.  The builder is the reference's; the numbers are pinned
 # here so that a change of the generators or of the builder shows.
-SCENES = ["cornell", "viewer_diamond", "special", "mixed", "mesh", "instanced1000", "sponza_like", "glass_blob"]
+SCENES = ["cornell", "viewer_diamond", "viewer_diamond_1k", "special", "mixed", "mesh", "instanced1000", "sponza_like", "glass_blob"]
 
 
 def _nodes(a):

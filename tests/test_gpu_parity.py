@@ -26,6 +26,7 @@ CASES = [
     ("cornell", 64, 64, 8, 4, (1, 2)),                   # SPP > 1 inside one dispatch
     ("cornell", 64, 64, 1, 1, (1,)),                     # MAX_DEPTH = 1: no extension rays
     ("viewer_diamond", 160, 90, 8, 1, (1, 2, 3)),        # config 2: metal floor + 2 instances
+    ("viewer_diamond_1k", 160, 90, 8, 1, (1, 2, 3)),     # config 2b: the "~1k tris" diamond BASELINE.json words (968 triangles)
     ("special", 96, 72, 8, 1, (1, 2)),                   # dielectric box + metal + 528 light triangles
     ("mixed", 96, 64, 10, 1, (1, 2)),                    # thin lens (defocus 0.3), GGX, nested dielectrics
     ("mesh", 96, 64, 8, 1, (1, 2)),                      # OBJ cube instances, dielectric, big sphere light
@@ -357,6 +358,7 @@ def test_batched_dispatch_with_stripes(W, gpu_renderer):
     ("special", 80, 56, 8, (1, 2, 3), 3),
     ("mixed", 64, 48, 10, (1, 2), 2),
     ("instanced1000", 96, 54, 8, (1, 2, 3, 4), 2),
+    ("viewer_diamond_1k", 96, 54, 8, (1, 2, 3, 4), 4),
     ("sponza_like", 64, 36, 8, (1, 2), 2),
     ("glass_blob", 48, 27, 16, (1, 2), 1),
     ("cornell", 33, 21, 1, (1, 2), 2),                      # MAX_DEPTH = 1: no extension rays at all

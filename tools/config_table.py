@@ -16,6 +16,7 @@ import parity_util as pu  # noqa: E402
 CONFIGS = [
     ("1 cornell", "cornell", 512, 512, 4, 4, 1),                 # name, scene, w, h, frames, depth, cpu stripe divisor
     ("2 viewer+diamond", "viewer_diamond", 1280, 720, 16, 8, 1),
+    ("2b viewer+diamond, 968 tris", "viewer_diamond_1k", 1280, 720, 16, 8, 3),
     ("3 instanced x1000", "instanced1000", 1920, 1080, 64, 8, 27),
     ("4 sponza-like 263k tris", "sponza_like", 1920, 1080, 64, 8, 27),
     ("5 glass blob 205k tris", "glass_blob", 3840, 2160, 256, 16, 270),
