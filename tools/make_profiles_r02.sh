@@ -52,6 +52,10 @@ if [ "$WHAT" = big ] || [ "$WHAT" = all ]; then
   rm -rf $OUT/trace_glass
   unset MI355RT_WF_OVERLAP
 fi
+mkdir -p $R/tools/bin
+for t in valu_peak gather_peak; do   # calibration binaries (git-ignored): build on the box when they did not travel
+  [ -x $R/tools/bin/$t ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/bin/$t $R/tools/$t.hip 2>/dev/null
+done
 timeout -k 10 120 $R/tools/bin/valu_peak > $OUT/r02_valu_peak.txt 2>&1
 timeout -k 10 300 $R/tools/bin/gather_peak > $OUT/r02_gather_peak.txt 2>&1
 timeout -k 10 200 python3 $R/tools/clock_check.py $OUT/r02_clock_check.json > $OUT/clock_check.log 2>&1
