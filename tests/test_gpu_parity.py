@@ -410,6 +410,28 @@ def test_partial_node_staging_parity(W, oracle_lib, monkeypatch, scene, treelet,
     pu.assert_parity(r, cpu, check_output=False)
 
 
+@pytest.mark.parametrize("env,value", [("MI355RT_WF_OVERLAP", "0"), ("MI355RT_WF_BLOCK", "512"), ("MI355RT_SHADE_BLOCKS_PER_CU", "3")])
+def test_wavefront_launch_knobs_keep_parity(W, oracle_lib, monkeypatch, env, value):
+    """The launch-shape knobs of the wavefront form (trace kernels on one stream instead of two, 512-thread trace
+    workgroups, fewer shade workgroups) change scheduling only: accumulation and counters still equal the oracle's."""
+    monkeypatch.setenv(env, value)
+    b = pu.bridge_for(W, "instanced1000")
+    w, h, depth, frames = 80, 48, 8, (1, 2, 3, 4, 5)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
+    r = W.WebGPURenderer(0)
+    r.setKernelVariant(2)
+    r.buildPipeline(depth, 1)
+    W.upload_scene(r, b, w, h)
+    r.setCounting(True)
+    r.resetCounters()
+    r.computeBatch(list(frames[:3]))
+    r.computeBatch(list(frames[3:]))
+    r.sync()
+    pu.assert_parity(r, cpu, check_output=False)
+    r.destroy()
+
+
 @pytest.mark.parametrize("variant", [2, 3])
 def test_wavefront_form_with_stripes(W, gpu_renderer, variant):
     """Sharded render of a scene that does not fit LDS (auto = wavefront form): the ranks' stripes sum to the
