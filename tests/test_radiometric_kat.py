@@ -1,0 +1,192 @@
+"""A radiometric known answer, independent of any restatement: a closed box whose ceiling and four walls are emitters of
+radiance Le and whose floor is a Lambert surface of albedo rho.  Every path that leaves the floor ends on an emitter, so
+the radiance leaving the floor is exactly rho * Le (irradiance pi * Le times the BRDF rho / pi), whatever the mix of
+light sampling and BSDF sampling — provided the light pdf, the cosine pdf, the pick probability of a light triangle and the
+two power-heuristic weights are mutually consistent.  The reference's estimator (Raytracer.wgsl:345-427, 656-728) passes
+this if and only if those pieces are what they claim to be; a mis-restated pdf or weight in the oracle shows up as a bias
+of the mean, far outside the sampling error.  (GPU = oracle bit for bit, tests/test_gpu_parity.py.)"""
+import numpy as np
+import pytest
+
+import parity_util as pu  # noqa: F401  (sys.path set-up)
+import random_scene
+
+
+def furnace_floor_bridge(rho, le, emitters_face_inward=True, emitting=("ceiling", "x-", "x+", "z-", "z+"), transform=None):
+    """Box [-1, 1]^3: Lambert floor of albedo rho, the faces named in `emitting` are emitters of radiance le, the others
+    are black (Lambert, albedo 0).  `transform` (4x4, float64) places the box as an instance; the camera moves with it."""
+    quad = lambda a, b, c, d: [(a, b, c), (a, c, d)]
+    P = lambda x, y, z: (float(x), float(y), float(z))
+    # faces of the box [-1, 1]^3, wound so that cross(e1, e2) points INTO the box
+    faces = {
+        "floor":   quad(P(-1, -1, -1), P(-1, -1, 1), P(1, -1, 1), P(1, -1, -1)),
+        "ceiling": quad(P(-1, 1, -1), P(1, 1, -1), P(1, 1, 1), P(-1, 1, 1)),
+        "x-":      quad(P(-1, -1, -1), P(-1, 1, -1), P(-1, 1, 1), P(-1, -1, 1)),
+        "x+":      quad(P(1, -1, -1), P(1, -1, 1), P(1, 1, 1), P(1, 1, -1)),
+        "z-":      quad(P(-1, -1, -1), P(1, -1, -1), P(1, 1, -1), P(-1, 1, -1)),
+        "z+":      quad(P(-1, -1, 1), P(-1, 1, 1), P(1, 1, 1), P(1, -1, 1)),
+    }
+    tris, mats = [], []
+    for name, ts in faces.items():
+        for t in ts:
+            t = np.array(t, dtype=np.float32)
+            n = np.cross(t[1] - t[0], t[2] - t[0])
+            assert np.dot(n, -t.mean(axis=0)) > 0, name          # inward
+            if name in emitting and not emitters_face_inward:
+                t = t[[0, 2, 1]]
+            tris.append(t)
+            mats.append(3 if name in emitting else (0 if name == "floor" else -1))
+    tris = np.array(tris, dtype=np.float32)
+    nt = len(tris)
+    rng = np.random.default_rng(1)
+    bmin, bmax = tris.min(axis=1) - 1e-4, tris.max(axis=1) + 1e-4
+    order = np.arange(nt)
+    nodes = random_scene._build_bvh(bmin, bmax, order, rng, 4, lambda first, count: (first << 3) | count)
+    rows = np.zeros((nt, 20), dtype=np.uint32)
+    f = rows.view(np.float32)
+    lights = []
+    for pos, t in enumerate(order):
+        rows[pos, 0:3] = 3 * t + np.arange(3)
+        rows[pos, 3] = 0
+        f[pos, 4:7] = rho if mats[t] == 0 else (le if mats[t] == 3 else 0.0)
+        f[pos, 7] = float(max(mats[t], 0))
+        f[pos, 9] = 1.0
+        f[pos, 10] = 1.5
+        f[pos, 12:16] = -1.0
+        f[pos, 19] = -1.0
+        if mats[t] == 3:
+            lights += [0, pos]
+    V = tris.reshape(-1, 3)
+    vertices = np.concatenate([V, np.ones((len(V), 1), np.float32)], axis=1).reshape(-1)
+    N = np.repeat(np.array([np.cross(t[1] - t[0], t[2] - t[0]) for t in tris], dtype=np.float32), 3, axis=0)
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    normals = np.concatenate([N, np.zeros((len(N), 1), np.float32)], axis=1).astype(np.float32).reshape(-1)
+    M = np.eye(4) if transform is None else np.asarray(transform, dtype=np.float64)
+    m32 = M.astype(np.float32)
+    inv32 = np.linalg.inv(m32.astype(np.float64)).astype(np.float32)
+    inst = np.zeros(36, dtype=np.float32)
+    inst[0:16] = m32.T.reshape(-1)                        # column-major, like the bridge
+    inst[16:32] = inv32.T.reshape(-1)
+    corners = np.array([[x, y, z, 1.0] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)]) @ M.T
+    tl = random_scene._pack([[(corners[:, :3].min(axis=0) - 1e-3).astype(np.float32),
+                              (corners[:, :3].max(axis=0) + 1e-3).astype(np.float32), 1, (0 << 3) | 1]])
+    cam = np.zeros(24, dtype=np.float32)
+    A, t0 = M[:3, :3], M[:3, 3]
+    eye = (A @ np.array([0.0, 0.5, 0.0]) + t0).astype(np.float32)
+    h, v = (A @ np.array([0.8, 0, 0])).astype(np.float32), (A @ np.array([0, 0, 0.8])).astype(np.float32)
+    cam[0:3] = eye
+    cam[4:7] = eye + (A @ np.array([0, -1.0, 0])).astype(np.float32) - h / 2 - v / 2
+    cam[8:11], cam[12:15] = h, v
+    cam[16:19], cam[20:23] = h / np.linalg.norm(h), v / np.linalg.norm(v)   # forward = u x v: looking at the floor
+    return random_scene.Bridge(vertices=vertices, normals=normals, uvs=np.zeros(2 * len(V), np.float32),
+                               mesh_topology=rows.reshape(-1), tlas=tl, blas=random_scene._pack(nodes), instances=inst,
+                               lights=np.array(lights, dtype=np.uint32),
+                               draw_commands=np.array([nt * 3, 1, 0, 0], dtype=np.uint32), cameraData=cam, textures=None)
+
+
+def _mean_radiance(W, oracle_lib, b, w, h, n_frames):
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, 8, 1, tuple(range(1, n_frames + 1)), present=False)
+    acc = cpu.readAccum().astype(np.float64)
+    assert (acc[..., 3] == n_frames).all()
+    return acc[..., :3] / acc[..., 3:4], cpu.getCounters()
+
+
+def _placed():
+    """rotation about a skew axis x non-uniform scale + translation: light areas, cosines and distances all change"""
+    ax = np.array([0.3, 1.0, -0.5]); ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(0.7) * K + (1 - np.cos(0.7)) * (K @ K)
+    M = np.eye(4)
+    M[:3, :3] = R * 1.7                                    # uniform scale keeps rho * Le the exact answer (angles are preserved)
+    M[:3, 3] = [3.0, -2.0, 5.0]
+    return M
+
+
+@pytest.mark.parametrize("inward,transform", [(True, None), (False, None), (True, "placed")])
+def test_lambert_floor_in_an_emitting_box(W, oracle_lib, inward, transform):
+    """Mean radiance of the floor = rho * Le per channel.  inward = True: light sampling and BSDF sampling both reach the
+    emitters and are combined by the power heuristic; False: the emitters' geometric normals point outward, the one-sided
+    light pdf (Raytracer.wgsl:372-375) is zero everywhere and BSDF sampling alone must give the same answer."""
+    rho = np.array([128, 204, 51], dtype=np.float32) / np.float32(255)     # exact in the G-buffer's rgba8unorm albedo
+    le = np.array([2.0, 1.0, 0.5], dtype=np.float32)
+    b = furnace_floor_bridge(rho, le, inward, transform=_placed() if transform else None)
+    w = h = 48
+    frames = tuple(range(1, 65))
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, 8, 1, frames, present=False)
+    acc = cpu.readAccum().astype(np.float64)
+    assert (acc[..., 3] == len(frames)).all()
+    per_pixel = acc[..., :3] / acc[..., 3:4]
+    mean = per_pixel.mean(axis=(0, 1))
+    stderr = per_pixel.std(axis=(0, 1)) / np.sqrt(w * h)
+    expected = rho.astype(np.float64) * le
+    assert np.all(np.abs(mean - expected) < np.maximum(6 * stderr, 2e-3 * expected)), (mean, expected, stderr)
+    assert np.all(np.abs(mean / expected - 1.0) < 0.01), (mean, expected)
+    c = cpu.getCounters()
+    assert c["primary_rays"] == w * h * len(frames)
+    if inward:
+        assert c["shadow_rays"] > 0.9 * c["primary_rays"]
+    else:
+        assert c["shadow_rays"] == 0
+
+
+def _corner_form_factor(a, b, c):
+    """differential area -> parallel rectangle a x b at distance c, the element under one CORNER of the rectangle (the
+    classic closed form, Howell's catalogue of configuration factors B-4):
+    F = 1 / (2 pi) [ a / sqrt(a^2 + c^2) atan(b / sqrt(a^2 + c^2)) + b / sqrt(b^2 + c^2) atan(a / sqrt(b^2 + c^2)) ]"""
+    a, b = np.abs(a), np.abs(b)
+    ra, rb = np.sqrt(a * a + c * c), np.sqrt(b * b + c * c)
+    return (a / ra * np.arctan(b / ra) + b / rb * np.arctan(a / rb)) / (2 * np.pi)
+
+
+def _ceiling_form_factor(x, z):
+    """floor point (x, -1, z) -> the ceiling square [-1, 1]^2 at height 2: four corner rectangles"""
+    c = 2.0
+    return sum(_corner_form_factor(1 - sx * x, 1 - sz * z, c) for sx in (-1, 1) for sz in (-1, 1))   # |x|, |z| < 1
+
+
+def test_lambert_floor_under_a_square_light(W, oracle_lib):
+    """Only the ceiling emits; the walls are black.  The floor's radiance is rho * Le * F(x), F the point-to-rectangle
+    form factor — direct light only, so this pins the light-sampling estimator (pick probability, area pdf, cosine at
+    the light, shadow-ray visibility) and its MIS partner against geometry worked out on paper."""
+    rho = np.array([255, 153, 102], dtype=np.float32) / np.float32(255)
+    le = np.array([3.0, 2.0, 1.0], dtype=np.float32)
+    b = furnace_floor_bridge(rho, le, True, emitting=("ceiling",))
+    w = h = 48
+    per_pixel, c = _mean_radiance(W, oracle_lib, b, w, h, 96)
+    # floor point behind every pixel centre (bench camera convention: u = (x + .5) / w, v = 1 - (y + .5) / h)
+    cam = b.cameraData.astype(np.float64)
+    eye, ll, hv, vv = cam[0:3], cam[4:7], cam[8:11], cam[12:15]
+    xs, ys = np.meshgrid((np.arange(w) + 0.5) / w, 1.0 - (np.arange(h) + 0.5) / h)
+    d = ll[None, None, :] + xs[..., None] * hv + ys[..., None] * vv - eye
+    t = (-1.0 - eye[1]) / d[..., 1]
+    px, pz = eye[0] + t * d[..., 0], eye[2] + t * d[..., 2]
+    F = _ceiling_form_factor(px, pz)
+    assert 0.15 < F.min() and F.max() < 0.25          # ~0.24 under the centre of the light
+    expected = F[..., None] * (rho.astype(np.float64) * le)[None, None, :]
+    ratio = per_pixel.mean(axis=(0, 1)) / expected.mean(axis=(0, 1))
+    stderr = per_pixel.std(axis=(0, 1)) / np.sqrt(w * h) / expected.mean(axis=(0, 1))
+    assert np.all(np.abs(ratio - 1.0) < np.maximum(5 * stderr, 3e-3)), (ratio, stderr)
+    # and pixel by pixel, within the noise of 96 samples: no systematic tilt across the image
+    rel = (per_pixel - expected) / expected
+    assert np.abs(rel[: h // 2].mean() - rel[h // 2:].mean()) < 0.02
+    assert np.abs(rel[:, : w // 2].mean() - rel[:, w // 2:].mean()) < 0.02
+    assert c["shadow_rays"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["box", "box_outward", "box_placed", "square_light"])
+def test_gpu_equals_oracle_on_the_radiometric_scenes(W, oracle_lib, gpu_renderer, case):
+    """The same scenes on the HIP path: bit-identical to the oracle (so the known answers above hold for it too)."""
+    rho = np.array([128, 204, 51], dtype=np.float32) / np.float32(255)
+    le = np.array([2.0, 1.0, 0.5], dtype=np.float32)
+    b = {"box": lambda: furnace_floor_bridge(rho, le, True),
+         "box_outward": lambda: furnace_floor_bridge(rho, le, False),
+         "box_placed": lambda: furnace_floor_bridge(rho, le, True, transform=_placed()),
+         "square_light": lambda: furnace_floor_bridge(rho, le, True, emitting=("ceiling",))}[case]()
+    frames = tuple(range(1, 9))
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, 48, 48, 8, 1, frames, present=True)
+    pu.drive(gpu_renderer, W, b, 48, 48, 8, 1, frames, present=True)
+    pu.assert_parity(gpu_renderer, cpu, check_output=True)
