@@ -25,3 +25,13 @@ def oracle_lib():
     import oracle_lib as ol
     ol.build_oracle()
     return ol
+
+
+@pytest.fixture()
+def gpu_renderer(W):
+    """A fresh context per test: totalFrames (the Halton jitter index) is renderer-lifetime state
+    (WebGPURenderer.ts:15,89), so parity with a fresh oracle needs a fresh renderer."""
+    W._build.build_rt()
+    r = W.WebGPURenderer(0)
+    yield r
+    r.destroy()

@@ -9,16 +9,6 @@ import parity_util as pu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def gpu_renderer(W):
-    """A fresh context per test: totalFrames (the Halton jitter index) is renderer-lifetime state
-    (WebGPURenderer.ts:15,89), so parity with a fresh oracle needs a fresh renderer."""
-    W._build.build_rt()
-    r = W.WebGPURenderer(0)
-    yield r
-    r.destroy()
-
-
 CASES = [
     # scene, w, h, depth, spp, frames
     ("cornell", 128, 128, 4, 1, (1, 2, 3, 4)),          # BASELINE config 1, reduced resolution
