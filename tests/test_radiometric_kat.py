@@ -12,31 +12,22 @@ import parity_util as pu  # noqa: F401  (sys.path set-up)
 import random_scene
 
 
-def furnace_floor_bridge(rho, le, emitters_face_inward=True, emitting=("ceiling", "x-", "x+", "z-", "z+"), transform=None):
-    """Box [-1, 1]^3: Lambert floor of albedo rho, the faces named in `emitting` are emitters of radiance le, the others
-    are black (Lambert, albedo 0).  `transform` (4x4, float64) places the box as an instance; the camera moves with it."""
-    quad = lambda a, b, c, d: [(a, b, c), (a, c, d)]
-    P = lambda x, y, z: (float(x), float(y), float(z))
-    # faces of the box [-1, 1]^3, wound so that cross(e1, e2) points INTO the box
-    faces = {
-        "floor":   quad(P(-1, -1, -1), P(-1, -1, 1), P(1, -1, 1), P(1, -1, -1)),
-        "ceiling": quad(P(-1, 1, -1), P(1, 1, -1), P(1, 1, 1), P(-1, 1, 1)),
-        "x-":      quad(P(-1, -1, -1), P(-1, 1, -1), P(-1, 1, 1), P(-1, -1, 1)),
-        "x+":      quad(P(1, -1, -1), P(1, -1, 1), P(1, 1, 1), P(1, 1, -1)),
-        "z-":      quad(P(-1, -1, -1), P(1, -1, -1), P(1, 1, -1), P(-1, 1, -1)),
-        "z+":      quad(P(-1, -1, 1), P(-1, 1, 1), P(1, 1, 1), P(1, -1, 1)),
-    }
-    tris, mats = [], []
-    for name, ts in faces.items():
-        for t in ts:
-            t = np.array(t, dtype=np.float32)
-            n = np.cross(t[1] - t[0], t[2] - t[0])
-            assert np.dot(n, -t.mean(axis=0)) > 0, name          # inward
-            if name in emitting and not emitters_face_inward:
-                t = t[[0, 2, 1]]
-            tris.append(t)
-            mats.append(3 if name in emitting else (0 if name == "floor" else -1))
-    tris = np.array(tris, dtype=np.float32)
+_QUAD = lambda a, b, c, d: [(a, b, c), (a, c, d)]
+_BOX_FACES = {   # faces of the box [-1, 1]^3, wound so that cross(e1, e2) points INTO the box
+    "floor":   _QUAD((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1)),
+    "ceiling": _QUAD((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)),
+    "x-":      _QUAD((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1)),
+    "x+":      _QUAD((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1)),
+    "z-":      _QUAD((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)),
+    "z+":      _QUAD((-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1)),
+}
+
+
+def bridge_from_triangles(tris, mats, colours, iors=None, transform=None, eye=(0.0, 0.5, 0.0)):
+    """One geometry, one instance, in the bridge layout.  tris: (n, 3, 3); mats: 0 Lambert / 2 dielectric / 3 emitter;
+    colours: (n, 3) albedo or emitted radiance.  The camera sits at `eye` (object space) and looks straight down at a
+    0.8 x 0.8 window one unit below it; `transform` (4x4) places geometry and camera together."""
+    tris = np.asarray(tris, dtype=np.float32)
     nt = len(tris)
     rng = np.random.default_rng(1)
     bmin, bmax = tris.min(axis=1) - 1e-4, tris.max(axis=1) + 1e-4
@@ -47,11 +38,10 @@ def furnace_floor_bridge(rho, le, emitters_face_inward=True, emitting=("ceiling"
     lights = []
     for pos, t in enumerate(order):
         rows[pos, 0:3] = 3 * t + np.arange(3)
-        rows[pos, 3] = 0
-        f[pos, 4:7] = rho if mats[t] == 0 else (le if mats[t] == 3 else 0.0)
-        f[pos, 7] = float(max(mats[t], 0))
+        f[pos, 4:7] = colours[t]
+        f[pos, 7] = float(mats[t])
         f[pos, 9] = 1.0
-        f[pos, 10] = 1.5
+        f[pos, 10] = 1.5 if iors is None else iors[t]
         f[pos, 12:16] = -1.0
         f[pos, 19] = -1.0
         if mats[t] == 3:
@@ -67,21 +57,39 @@ def furnace_floor_bridge(rho, le, emitters_face_inward=True, emitting=("ceiling"
     inst = np.zeros(36, dtype=np.float32)
     inst[0:16] = m32.T.reshape(-1)                        # column-major, like the bridge
     inst[16:32] = inv32.T.reshape(-1)
-    corners = np.array([[x, y, z, 1.0] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)]) @ M.T
+    lo, hi = V.min(axis=0), V.max(axis=0)
+    corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]) @ M.T
     tl = random_scene._pack([[(corners[:, :3].min(axis=0) - 1e-3).astype(np.float32),
                               (corners[:, :3].max(axis=0) + 1e-3).astype(np.float32), 1, (0 << 3) | 1]])
     cam = np.zeros(24, dtype=np.float32)
     A, t0 = M[:3, :3], M[:3, 3]
-    eye = (A @ np.array([0.0, 0.5, 0.0]) + t0).astype(np.float32)
+    e = (A @ np.array(eye, dtype=np.float64) + t0).astype(np.float32)
     h, v = (A @ np.array([0.8, 0, 0])).astype(np.float32), (A @ np.array([0, 0, 0.8])).astype(np.float32)
-    cam[0:3] = eye
-    cam[4:7] = eye + (A @ np.array([0, -1.0, 0])).astype(np.float32) - h / 2 - v / 2
+    cam[0:3] = e
+    cam[4:7] = e + (A @ np.array([0, -1.0, 0])).astype(np.float32) - h / 2 - v / 2
     cam[8:11], cam[12:15] = h, v
-    cam[16:19], cam[20:23] = h / np.linalg.norm(h), v / np.linalg.norm(v)   # forward = u x v: looking at the floor
+    cam[16:19], cam[20:23] = h / np.linalg.norm(h), v / np.linalg.norm(v)   # forward = u x v: looking down
     return random_scene.Bridge(vertices=vertices, normals=normals, uvs=np.zeros(2 * len(V), np.float32),
                                mesh_topology=rows.reshape(-1), tlas=tl, blas=random_scene._pack(nodes), instances=inst,
                                lights=np.array(lights, dtype=np.uint32),
                                draw_commands=np.array([nt * 3, 1, 0, 0], dtype=np.uint32), cameraData=cam, textures=None)
+
+
+def furnace_floor_bridge(rho, le, emitters_face_inward=True, emitting=("ceiling", "x-", "x+", "z-", "z+"), transform=None):
+    """Box [-1, 1]^3: Lambert floor of albedo rho, the faces named in `emitting` are emitters of radiance le, the others
+    are black (Lambert, albedo 0).  `transform` (4x4, float64) places the box as an instance; the camera moves with it."""
+    tris, mats, colours = [], [], []
+    for name, ts in _BOX_FACES.items():
+        for t in ts:
+            t = np.array(t, dtype=np.float32)
+            n = np.cross(t[1] - t[0], t[2] - t[0])
+            assert np.dot(n, -t.mean(axis=0)) > 0, name          # inward
+            if name in emitting and not emitters_face_inward:
+                t = t[[0, 2, 1]]
+            tris.append(t)
+            mats.append(3 if name in emitting else 0)
+            colours.append(le if name in emitting else (rho if name == "floor" else np.zeros(3, np.float32)))
+    return bridge_from_triangles(tris, mats, colours, transform=transform)
 
 
 def _mean_radiance(W, oracle_lib, b, w, h, n_frames):
@@ -176,7 +184,7 @@ def test_lambert_floor_under_a_square_light(W, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["box", "box_outward", "box_placed", "square_light"])
+@pytest.mark.parametrize("case", ["box", "box_outward", "box_placed", "square_light", "glass_slab"])
 def test_gpu_equals_oracle_on_the_radiometric_scenes(W, oracle_lib, gpu_renderer, case):
     """The same scenes on the HIP path: bit-identical to the oracle (so the known answers above hold for it too)."""
     rho = np.array([128, 204, 51], dtype=np.float32) / np.float32(255)
@@ -184,9 +192,64 @@ def test_gpu_equals_oracle_on_the_radiometric_scenes(W, oracle_lib, gpu_renderer
     b = {"box": lambda: furnace_floor_bridge(rho, le, True),
          "box_outward": lambda: furnace_floor_bridge(rho, le, False),
          "box_placed": lambda: furnace_floor_bridge(rho, le, True, transform=_placed()),
-         "square_light": lambda: furnace_floor_bridge(rho, le, True, emitting=("ceiling",))}[case]()
+         "square_light": lambda: furnace_floor_bridge(rho, le, True, emitting=("ceiling",)),
+         "glass_slab": lambda: glass_slab_bridge(le)}[case]()
     frames = tuple(range(1, 9))
     cpu = oracle_lib.OracleRenderer()
     pu.drive(cpu, W, b, 48, 48, 8, 1, frames, present=True)
     pu.drive(gpu_renderer, W, b, 48, 48, 8, 1, frames, present=True)
     pu.assert_parity(gpu_renderer, cpu, check_output=True)
+
+
+def glass_slab_bridge(le, ior=1.5):
+    """The box with an emitting ceiling, black walls and floor, and a white glass slab (y in [-0.2, 0]) spanning it: the
+    camera (y = 0.5) looks down at the slab; what it sees of the ceiling is the slab's reflectance."""
+    tris, mats, colours, iors = [], [], [], []
+    for name, ts in _BOX_FACES.items():
+        for t in ts:
+            tris.append(np.array(t, dtype=np.float32))
+            mats.append(3 if name == "ceiling" else 0)
+            colours.append(le if name == "ceiling" else np.zeros(3, np.float32))
+            iors.append(1.5)
+    for y, up in ((0.0, True), (-0.2, False)):
+        q = _QUAD((-1, y, -1), (-1, y, 1), (1, y, 1), (1, y, -1)) if up else _QUAD((-1, y, -1), (1, y, -1), (1, y, 1), (-1, y, 1))
+        for t in q:
+            t = np.array(t, dtype=np.float32)
+            assert (np.cross(t[1] - t[0], t[2] - t[0])[1] > 0) == up      # outward normals of the slab
+            tris.append(t)
+            mats.append(2)
+            colours.append(np.ones(3, np.float32))
+            iors.append(ior)
+    return bridge_from_triangles(tris, mats, colours, iors)
+
+
+def test_glass_slab_reflectance(W, oracle_lib):
+    """A white dielectric slab over a black floor under an emitting ceiling shows Le times its reflectance.  With the
+    reference's Schlick reflectance at BOTH interfaces (Raytracer.wgsl:314-339; the cosine is the one on the incident
+    side, inside the glass too) the geometric series of internal reflections sums to
+    R = R1 + (1 - R1) R2 / (1 + R2), R1 = schlick(cos theta), R2 = schlick(cos theta') with Snell's theta'.
+    Pins the branch probability of the dielectric (reflect with probability R, one RNG draw), its unit throughput, the
+    refraction direction (theta' enters R2) and that glass blocks the floor's shadow rays."""
+    le = np.array([4.0, 2.0, 1.0], dtype=np.float32)
+    ior = 1.5
+    b = glass_slab_bridge(le, ior)
+    w = h = 48
+    per_pixel, c = _mean_radiance(W, oracle_lib, b, w, h, 256)
+    cam = b.cameraData.astype(np.float64)
+    eye, ll, hv, vv = cam[0:3], cam[4:7], cam[8:11], cam[12:15]
+    xs, ys = np.meshgrid((np.arange(w) + 0.5) / w, 1.0 - (np.arange(h) + 0.5) / h)
+    d = ll[None, None, :] + xs[..., None] * hv + ys[..., None] * vv - eye
+    cos_t = -d[..., 1] / np.linalg.norm(d, axis=-1)
+    sin_in = np.sqrt(1 - cos_t ** 2) / ior
+    cos_in = np.sqrt(1 - sin_in ** 2)
+    r0 = ((1 - ior) / (1 + ior)) ** 2
+    schlick = lambda cs: r0 + (1 - r0) * (1 - cs) ** 5
+    R1, R2 = schlick(cos_t), schlick(cos_in)
+    R = R1 + (1 - R1) * R2 / (1 + R2)
+    assert 0.0769 < R.min() and R.max() < 0.0771          # 2 r0 / (1 + r0) = 0.076923 at these angles
+    expected = R[..., None] * le.astype(np.float64)[None, None, :]
+    ratio = per_pixel.mean(axis=(0, 1)) / expected.mean(axis=(0, 1))
+    stderr = per_pixel.std(axis=(0, 1)) / np.sqrt(w * h) / expected.mean(axis=(0, 1))
+    assert np.all(stderr < 0.01)
+    assert np.all(np.abs(ratio - 1.0) < 5 * stderr), (ratio, stderr)
+    assert c["shadow_rays"] > 0      # the floor tries next-event estimation; the slab is in the way
