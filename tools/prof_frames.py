@@ -19,12 +19,10 @@ detailed = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 ranks = int(sys.argv[8]) if len(sys.argv) > 8 else 1   # render only rank 0 of N interleaved 16-row stripes
 batch = int(sys.argv[9]) if len(sys.argv) > 9 else 1   # frames per batched dispatch
 
-b = W.WorldBridge()
-if scene == "viewer_diamond":
-    b.loadScene("viewer", "v 0 1 0\nv 1 0 0\nv 0 0 1\nv -1 0 0\nv 0 0 -1\nv 0 -1 0\n"
-                "f 1 3 2\nf 1 2 5\nf 1 5 4\nf 1 4 3\nf 6 2 3\nf 6 5 2\nf 6 4 5\nf 6 3 4\n")
-else:
-    b.loadScene(scene)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import parity_util as pu  # noqa: E402  (scene names as in the tests: viewer_diamond, viewer_diamond_1k, ...)
+
+b = pu.bridge_for(W, scene)
 r = W.WebGPURenderer(0)
 r.buildPipeline(depth, 1)
 W.upload_scene(r, b, w, h)
