@@ -400,6 +400,27 @@ def test_partial_node_staging_parity(W, oracle_lib, monkeypatch, scene, treelet,
     pu.assert_parity(r, cpu, check_output=False)
 
 
+@pytest.mark.parametrize("scene,variant", [("cornell", 1), ("cornell", 2), ("mesh", 2), ("special", 1), ("mixed", 2), ("viewer_diamond", 3)])
+def test_global_paths_on_small_scenes(W, oracle_lib, monkeypatch, scene, variant):
+    """MI355RT_NO_LDS_STAGING=1: small scenes through the code the big ones use — nodes, triangle records and instance
+    rows read through the L1, instance entries deferred and batched — with the oracle's result, counters included."""
+    monkeypatch.setenv("MI355RT_NO_LDS_STAGING", "1")
+    b = pu.bridge_for(W, scene)
+    w, h, depth, frames = 72, 48, 8, (1, 2, 3, 4)
+    cpu = oracle_lib.OracleRenderer()
+    pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
+    r = W.WebGPURenderer(0)
+    r.setKernelVariant(variant)
+    r.buildPipeline(depth, 1)
+    W.upload_scene(r, b, w, h)
+    r.setCounting(True)
+    r.resetCounters()
+    r.computeBatch(list(frames))
+    r.sync()
+    pu.assert_parity(r, cpu, check_output=False)
+    r.destroy()
+
+
 @pytest.mark.parametrize("env,value", [("MI355RT_WF_OVERLAP", "0"), ("MI355RT_WF_BLOCK", "512"), ("MI355RT_SHADE_BLOCKS_PER_CU", "3")])
 def test_wavefront_launch_knobs_keep_parity(W, oracle_lib, monkeypatch, env, value):
     """The launch-shape knobs of the wavefront form (trace kernels on one stream instead of two, 512-thread trace

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Extended GPU / oracle parity sweep over random bridge-layout scenes (tests/random_scene.py): every kernel form,
-batched dispatches, textures, thin lens.  usage: fuzz_parity_sweep.py [first_seed] [count]"""
+batched dispatches, textures, thin lens.  usage: fuzz_parity_sweep.py [first_seed] [count]
+With MI355RT_NO_LDS_STAGING=1 in the environment the same scenes go through the global-memory code paths (mixed-mode walk,
+deferred instance entry) that scenes of this size otherwise never reach."""
 import os
 import sys
 

@@ -51,6 +51,8 @@ struct rt_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   bool wf_overlap = true;
+  int shade_per_cu = 16;         // workgroups per CU of the wavefront shade kernels (MI355RT_SHADE_BLOCKS_PER_CU)
+  bool no_lds_staging = false;   // MI355RT_NO_LDS_STAGING=1 (test hook): every record through the global-memory paths
   std::string error;
 
   // scene buffers (raw bridge layout)
@@ -441,6 +443,8 @@ rt_ctx* rt_create(int device_ordinal) {
     return nullptr;
   }
   if (const char* e = getenv("MI355RT_WF_OVERLAP")) c->wf_overlap = atoi(e) != 0;
+  if (const char* e = getenv("MI355RT_NO_LDS_STAGING")) c->no_lds_staging = atoi(e) != 0;
+  if (const char* e = getenv("MI355RT_SHADE_BLOCKS_PER_CU")) c->shade_per_cu = std::max(1, std::min(4096, atoi(e)));
   if (const char* e = getenv("MI355RT_WF_BLOCK")) {
     const int b = atoi(e);
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
@@ -908,6 +912,10 @@ int rt_recreate_bind_group(rt_ctx* c) { return c ? RT_OK : RT_ERR_INVALID; }
 static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes, size_t* dyn_bytes) {
   rtk::LdsPlan P;
   P.k_nodes = P.stage_inst = P.stage_tri = P.pad = 0;
+  if (c->no_lds_staging) {
+    *dyn_bytes = queue_bytes;
+    return P;
+  }
   budget &= ~(size_t)2047;   // LDS is allocated in granules: leave room so that the intended number of workgroups fits a CU
   size_t avail = budget > queue_bytes ? budget - queue_bytes : 0;
   avail &= ~(size_t)15;
@@ -953,9 +961,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   if (r < 0) return r;
   // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
   // shade kernels: persistent waves that loop over the items; every wave may leave one partly used chunk per queue
-  int shade_per_cu = 16;
-  if (const char* e = getenv("MI355RT_SHADE_BLOCKS_PER_CU")) shade_per_cu = std::max(1, std::min(4096, atoi(e)));
-  const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * (size_t)shade_per_cu);
+  const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * (size_t)c->shade_per_cu);
   const size_t qcap = items + (size_t)shade_blocks * 4 * 256 + 1024 * 1024;
   // per item: active[2] + shadow ids + ext ids + occlusion word (5 x 4 B) + shadow rays, extension rays (2 x 32 B) + hits (16 B)
   r = ensure_buffer(c, c->wf_queues, qcap * 100, false);
@@ -982,7 +988,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
   // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
   const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
-  const bool trace_lds = fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  const bool trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
   if (!trace_lds) {
     block = c->wf_block ? c->wf_block : 256;
@@ -1098,7 +1104,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
 
   const size_t npx = (size_t)c->width * c->height;
   const size_t scene_lds = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
-  const bool fits_lds = scene_lds + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  const bool fits_lds = !c->no_lds_staging && scene_lds + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
   // auto: the wavefront form pays from 4 frames per dispatch (measured: 1 frame 11.9 vs 8.7 ms persistent, 2: 17.0 vs
   // 15.7, 4: 27.8 vs 29.5, 8: 47.9 vs 57.0 on sponza-like) — a single frame leaves its deeper stages too few rays
   const bool wavefront = c->spp == 1 && (c->variant == 2 || (c->variant == 3 && !fits_lds && n >= 4));
@@ -1174,7 +1180,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   {
     const size_t plds = rtk::primary_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts) * 16;
     const uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances, nv = c->n_verts;
-    if (plds <= 32 * 1024) {  // small scene: records staged in LDS, four tiles per workgroup
+    if (plds <= 32 * 1024 && !c->no_lds_staging) {  // small scene: records staged in LDS, four tiles per workgroup
       const dim3 grid((ptiles + 3) / 4, n);
       if (c->detailed_counters)
         hipLaunchKernelGGL((rtk::k_primary_visibility<true, true>), grid, dim3(256), plds, c->stream, S, Fp, c->uniforms, dslots, ptiles, nn, nt, ni, nv);
@@ -1204,7 +1210,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     // persistent kernel: grid = resident workgroups, tiles handed out through a ticket counter
     HIP_TRY(c, hipMemsetAsync(c->ticket.ptr, 0, 4, c->stream));
     const size_t lds_bytes = rtk::scene_lds_slots(c->n_nodes, c->n_tris, c->n_instances, c->n_verts, c->n_lights) * 16;
-    const bool use_lds = lds_bytes + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+    const bool use_lds = !c->no_lds_staging && lds_bytes + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
     size_t dyn = (size_t)4 * RT_WORK_BYTES_PER_WAVE + lds_bytes;  // work queues + records
     rtk::LdsPlan plan;
     plan.k_nodes = c->n_nodes;
