@@ -1,5 +1,5 @@
 #!/bin/bash
-for w in 4 5 6 8; do
+for w in 2 3 4 5 6 8; do
 python - <<PY
 import webgpu_raytracer_amd as W
 W._build.build_rt(force=True, extra_flags=["-DRT_SHADE_WAVES=$w"])
