@@ -27,8 +27,9 @@ __device__ __forceinline__ float rt_opaque(float v) {
 }
 
 // Where the traversal records live.  `tnodes` (k_treelet.hip.h) has its first k_lds nodes staged in LDS at slot l_nodes
-// of the workgroup's dynamic LDS array; the triangle records, the instance rows and the instance BLAS roots are staged
-// as a whole when they fit (l_* != RT_LDS_NONE), else read through L1 / L2.  Slots are 16-byte units.
+// of the workgroup's dynamic LDS array (by default all of them or none, rt_api.hip plan_lds); the triangle records, the
+// instance rows and the instance BLAS roots are staged as a whole when they fit (l_* != RT_LDS_NONE), else read through
+// L1 / L2.  Slots are 16-byte units.
 #define RT_LDS_NONE 0xffffffffu
 struct TravMem {
   const f4* gnodes;           // tnodes, 2 per node

@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 // results stream out by queue slot — ANY (shadow rays): one occlusion word; else (extension rays): {t, triangle,
 // instance} of the closest hit.  The path state is not touched here.  Ray-level regeneration: a lane whose ray is
 // finished writes its result and, when >= RT_WF_REFILL lanes are idle, the wave pulls the next rays of its chunk.
-// BLOCK threads per workgroup (256 / 512 / 1024): a bigger workgroup shares one staged treelet among more waves, so
-// the LDS copy of the top of the tree can be larger (LdsPlan, rt_api.hip plan_lds) at the price of fewer waves per SIMD
-// than the 256-thread form allows.  LDS = true: every traversal record fits (RT_TRAV_LDS).
+// BLOCK threads per workgroup (256 / 512 / 1024; 256 x 6 per CU by default): a bigger workgroup shares one staged copy of
+// the records among more waves at the price of fewer waves per SIMD (LdsPlan, rt_api.hip plan_lds; measured without gain,
+// DESIGN.md 4.1b).  LDS = true: every traversal record fits (RT_TRAV_LDS).
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 6
 #endif

@@ -985,8 +985,8 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   Q.counters = (uint32_t*)c->wf_counters.ptr;
   const bool detail = c->detailed_counters;
   // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
-  // records in LDS.  Otherwise ONE large workgroup per CU shares the biggest treelet the 160 KB allow (MI355RT_WF_BLOCK /
-  // MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps).
+  // records in LDS.  Otherwise six 256-thread workgroups per CU (6 waves per SIMD), each staging what fits whole in its
+  // sixth of the LDS (plan_lds); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
   const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
   const bool trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
