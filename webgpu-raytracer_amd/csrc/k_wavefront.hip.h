@@ -22,7 +22,7 @@ namespace rtk {
 // the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
 // Restriction: SPP == 1 (the reference's default); other SPP values use the persistent kernel.
 #ifndef RT_WF_REFILL
-#define RT_WF_REFILL 16
+#define RT_WF_REFILL 24   // idle lanes that trigger a pull; re-swept with RT_WF_STEPS_PER_TRIP on the final kernels (below)
 #endif
 
 // Device queues are filled and drained in chunks of RT_WF_CHUNK entries: a wave reserves a chunk with ONE atomic
@@ -235,8 +235,11 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 #define RT_WF_WAVES 6
 #endif
 #ifndef RT_WF_STEPS_PER_TRIP
-#define RT_WF_STEPS_PER_TRIP 4   // node steps between two looks at the ray queue and the triangle queue; swept on sponza-like
-                                 // (ms per 32 frames): 1: 153.0, 2: 137.7, 3: 134.5, 4: 133.2, 6: 132.0, 8: 131.4
+#define RT_WF_STEPS_PER_TRIP 6   // node steps between two looks at the ray queue and the triangle queue.  First sweep on
+                                 // sponza-like (ms per 32 frames): 1: 153.0, 2: 137.7, 3: 134.5, 4: 133.2, 6: 132.0, 8: 131.4.
+                                 // Final kernels, (steps, refill) -> ms per frame sponza-like / instanced x1000 / glass blob 4K:
+                                 // (4, 16) 4.39 / 2.93 / 10.32, (6, 16) 4.39 / 2.90 / 10.19, (6, 24) 4.31 / 2.95 / 10.11,
+                                 // (8, 24) 4.31 / 2.95 / 10.20, (6..12, 32..40) worse on instanced (up to +14 %)
 #endif
 // Diagnostic build only (-DRT_TRACE_STAMPS, tools/trace_sections.py): per-wave s_memtime cycles spent in the three
 // sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
