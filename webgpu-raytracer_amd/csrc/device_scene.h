@@ -80,14 +80,12 @@ struct DevFrameSlot {
 };
 
 // Wavefront form (large scenes): path state lives in HBM between the shade and trace stages.
-struct WfPath {       // one 96-B record per (frame, pixel) item: after the first bounce the live paths are visited in
-  float4 a;           // queue order, i.e. scattered — a record is three 32-B sectors instead of six planes' worth
-  float4 b;           // a: ro.xyz, hit_t   b: rd.xyz, prev_bsdf_pdf   c: throughput.xyz, bitcast(rng)
-  float4 c;           // d: radiance.xyz, bitcast(flags): depth | specular << 8 | ended << 9 | nee_valid << 10
-  float4 d;           // e: pending NEE term .xyz, bitcast(tri)
-  float4 e;
-  uint4 m;            // m: instance of the current surface, queue slot of the pending shadow ray, of the extension ray
-};
+struct WfPath {       // one 64-B record (one half cache line) per (frame, pixel) item; after the first bounce the live
+  float4 c;           // paths are visited in queue order, i.e. scattered.  The ray itself is NOT here: the extension ray a
+  float4 d;           // path continues along is in the ray queue at the path's slot (k_wf_shade reads it back from there).
+  float4 e;           // c: throughput.xyz, bitcast(rng)   d: radiance.xyz, bitcast(flags): depth | specular << 8 |
+  uint4 m;            // ended << 9 | nee_valid << 10   e: pending NEE term .xyz, prev_bsdf_pdf
+};                    // m: queue slot of the pending shadow ray, of the extension ray, 0, 0
 struct WfState {
   WfPath* p;
 };
@@ -97,7 +95,8 @@ struct WfQueues {
   float4* shadow_rays;    // ... and {o.xyz, t_max} {d.xyz, 0}
   uint32_t* occluded;     // ... result of k_wf_trace<any hit>, by slot: 1 = something is in the way
   uint32_t* ext_ids;      // extension-ray queue: path id ...
-  float4* ext_rays;       // ... {o.xyz, 0} {d.xyz, 0}
+  float4* ext_rays[2];    // ... {o.xyz, 0} {d.xyz, 0}; [depth & 1]: the shade pass of depth d + 1 reads the rays of depth d
+                          // (they are the path's ray: WfPath does not repeat it) while it queues its own
   float4* ext_hit;        // ... result of k_wf_trace<closest hit>, by slot: {t, bits(triangle), bits(instance), 0}; instance < 0 = miss
   uint32_t* counters;     // 8 u32 per depth: n_active, n_shadow, n_ext, head_shadow, head_ext, 0, 0, 0
 };

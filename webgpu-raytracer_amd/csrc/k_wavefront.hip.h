@@ -9,14 +9,14 @@ namespace rtk {
 // For scenes whose traversal records do not fit LDS (hundreds of thousands of triangles, a thousand instances) a ray
 // visits 70+ nodes with a long tail, and the per-trip lockstep of the persistent kernel leaves 60 % of the lanes idle
 // while they wait on L2 / Infinity-Cache latency.  The wavefront form splits a bounce into stages with the path state in
-// HBM (one 96-B record per path, 288 GB to spare):
+// HBM (one 64-B record per path, 288 GB to spare):
 //   k_wf_shade   one lane per live path: picks up the results of the previous depth's rays by queue slot (pending NEE
 //                term, hit of the extension ray), surface frame + shade_bounce(); appends the shadow ray and the
 //                extension ray WITH their ray data to device queues (wave-aggregated atomics), finishes paths that end
 //   k_wf_trace   persistent waves, RAY-level regeneration: a lane that finishes its ray writes the result to the ray's
 //                queue slot and pulls the next ray of the queue (batched, >= RT_WF_REFILL lanes), so the slowest ray
 //                no longer holds 63 lanes; same node step / LDS triangle queue as traverse().  Rays in, results out,
-//                both streamed by slot: the 96-byte path records are never touched here.
+//                both streamed by slot: the path records are never touched here.
 // Stages of one depth run as separate launches in stream order; the host enqueues all depths without reading anything
 // back (queue sizes stay on the device).  Per path the arithmetic, RNG order and f32 addition order are unchanged, so
 // the result is bit-identical to the other forms; frame colours go through frame_col + k_accumulate_frames.
@@ -59,12 +59,10 @@ __device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* id
 
 __device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
                                               rt3 nee, uint32_t sslot, uint32_t eslot) {
-  W.p[id].a = make_float4(p.ro.x, p.ro.y, p.ro.z, p.hit_t);
-  W.p[id].b = make_float4(p.rd.x, p.rd.y, p.rd.z, p.prev_pdf);
   W.p[id].c = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
   W.p[id].d = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
-  W.p[id].e = make_float4(nee.x, nee.y, nee.z, rt_u2f(p.tri));
-  W.p[id].m = make_uint4(p.inst, sslot, eslot, 0u);
+  W.p[id].e = make_float4(nee.x, nee.y, nee.z, p.prev_pdf);
+  W.p[id].m = make_uint4(sslot, eslot, 0u, 0u);   // the extension ray (p.ro, p.rd) is in Q.ext_rays[depth & 1] at eslot
 }
 
 // One lane per path that is alive at `depth`.  FIRST: the paths start at the pixels of the batch (camera ray + G-buffer
@@ -153,28 +151,27 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
         setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
       }
     } else {
-      const float4 d = W.p[id].d;
-      const uint4 m = W.p[id].m;
+      const float4 d = W.p[id].d, e = W.p[id].e;
+      const uint4 m = W.p[id].m;     // m.x: slot of the shadow ray, m.y: slot of the extension ray
       const uint32_t fl = rt_f2u(d.w);
       p.radiance = xyz(d);
-      if (m.y != RT_WF_INVALID && (fl & WF_FLAG_NEE_VALID) != 0u && Q.occluded[m.y] == 0u) {
-        const float4 e = W.p[id].e;
+      if (m.x != RT_WF_INVALID && (fl & WF_FLAG_NEE_VALID) != 0u && Q.occluded[m.x] == 0u)
         p.radiance = p.radiance + xyz(e);  // radiance += pending NEE term (nothing is added when bsdf_pdf <= 0)
-      }
       float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       bool over = (fl & WF_FLAG_ENDED) != 0u;
       if (!over) {
-        h = Q.ext_hit[m.z];
+        h = Q.ext_hit[m.y];
         over = (int32_t)rt_f2u(h.z) < 0;  // miss: the path ends with what it has
       }
       if (over) {
         F.frame_col[id] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 1.0f);  // SPP == 1: col / 1
         live = false;
       } else {
-        const float4 a = W.p[id].a, b = W.p[id].b, c = W.p[id].c;
+        const float4* went = Q.ext_rays[(depth + 1u) & 1u];   // the previous depth's extension rays: the ray the path went along
+        const float4 a = went[2 * m.y], b = went[2 * m.y + 1], c = W.p[id].c;
         p.ro = xyz(a);
         p.rd = xyz(b);
-        p.prev_pdf = b.w;
+        p.prev_pdf = e.w;
         p.throughput = xyz(c);
         p.rng = rt_f2u(c.w);
         p.depth = (fl & 0xffu) + 1u;
@@ -199,8 +196,9 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
     const uint32_t eslot = wq_append(wq_ext, &cnt[2], Q.ext_ids, live && bo.want_extend);
     if (eslot != RT_WF_INVALID) {
       Q.ext_ids[eslot] = id;
-      Q.ext_rays[2 * eslot] = make_float4(p.ro.x, p.ro.y, p.ro.z, 0.0f);
-      Q.ext_rays[2 * eslot + 1] = make_float4(p.rd.x, p.rd.y, p.rd.z, 0.0f);
+      float4* out = Q.ext_rays[depth & 1u];
+      out[2 * eslot] = make_float4(p.ro.x, p.ro.y, p.ro.z, 0.0f);
+      out[2 * eslot + 1] = make_float4(p.rd.x, p.rd.y, p.rd.z, 0.0f);
     }
     // the path goes on to the next depth's shade pass when something is pending for it
     const uint32_t nslot = wq_append(wq_next, &next_count[0], next_active, live && (bo.want_shadow || bo.want_extend));
@@ -272,7 +270,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
   uint32_t* head = ANY ? &cnt[3] : &cnt[4];
   const uint32_t* ids = ANY ? Q.shadow_ids : Q.ext_ids;
-  const float4* rays = ANY ? Q.shadow_rays : Q.ext_rays;
+  const float4* rays = ANY ? Q.shadow_rays : Q.ext_rays[depth & 1u];
 
   // per-lane ray + traversal state
   bool have_ray = false;

@@ -963,8 +963,9 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   // shade kernels: persistent waves that loop over the items; every wave may leave one partly used chunk per queue
   const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * (size_t)c->shade_per_cu);
   const size_t qcap = items + (size_t)shade_blocks * 4 * 256 + 1024 * 1024;
-  // per item: active[2] + shadow ids + ext ids + occlusion word (5 x 4 B) + shadow rays, extension rays (2 x 32 B) + hits (16 B)
-  r = ensure_buffer(c, c->wf_queues, qcap * 100, false);
+  // per item: active[2] + shadow ids + ext ids + occlusion word (5 x 4 B) + shadow rays, extension rays of even and of odd
+  // depths (3 x 32 B) + hits (16 B)
+  r = ensure_buffer(c, c->wf_queues, qcap * 132, false);
   if (r < 0) return r;
   const uint32_t depths = c->max_depth ? c->max_depth : 1u;
   r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 2) * 32, false);
@@ -975,13 +976,14 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   WfQueues Q;
   char* qb = (char*)c->wf_queues.ptr;
   Q.shadow_rays = (float4*)qb;
-  Q.ext_rays = (float4*)(qb + qcap * 32);
-  Q.ext_hit = (float4*)(qb + qcap * 64);
-  Q.active[0] = (uint32_t*)(qb + qcap * 80);
-  Q.active[1] = (uint32_t*)(qb + qcap * 84);
-  Q.shadow_ids = (uint32_t*)(qb + qcap * 88);
-  Q.ext_ids = (uint32_t*)(qb + qcap * 92);
-  Q.occluded = (uint32_t*)(qb + qcap * 96);
+  Q.ext_rays[0] = (float4*)(qb + qcap * 32);
+  Q.ext_rays[1] = (float4*)(qb + qcap * 64);
+  Q.ext_hit = (float4*)(qb + qcap * 96);
+  Q.active[0] = (uint32_t*)(qb + qcap * 112);
+  Q.active[1] = (uint32_t*)(qb + qcap * 116);
+  Q.shadow_ids = (uint32_t*)(qb + qcap * 120);
+  Q.ext_ids = (uint32_t*)(qb + qcap * 124);
+  Q.occluded = (uint32_t*)(qb + qcap * 128);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
   const bool detail = c->detailed_counters;
   // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
