@@ -184,7 +184,7 @@ def test_lambert_floor_under_a_square_light(W, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["box", "box_outward", "box_placed", "square_light", "glass_slab"])
+@pytest.mark.parametrize("case", ["box", "box_outward", "box_placed", "square_light", "glass_slab", "metal_floor"])
 def test_gpu_equals_oracle_on_the_radiometric_scenes(W, oracle_lib, gpu_renderer, case):
     """The same scenes on the HIP path: bit-identical to the oracle (so the known answers above hold for it too)."""
     rho = np.array([128, 204, 51], dtype=np.float32) / np.float32(255)
@@ -193,7 +193,8 @@ def test_gpu_equals_oracle_on_the_radiometric_scenes(W, oracle_lib, gpu_renderer
          "box_outward": lambda: furnace_floor_bridge(rho, le, False),
          "box_placed": lambda: furnace_floor_bridge(rho, le, True, transform=_placed()),
          "square_light": lambda: furnace_floor_bridge(rho, le, True, emitting=("ceiling",)),
-         "glass_slab": lambda: glass_slab_bridge(le)}[case]()
+         "glass_slab": lambda: glass_slab_bridge(le),
+         "metal_floor": lambda: metal_floor_bridge(0.3)[0]}[case]()
     frames = tuple(range(1, 9))
     cpu = oracle_lib.OracleRenderer()
     pu.drive(cpu, W, b, 48, 48, 8, 1, frames, present=True)
@@ -253,3 +254,68 @@ def test_glass_slab_reflectance(W, oracle_lib):
     assert np.all(stderr < 0.01)
     assert np.all(np.abs(ratio - 1.0) < 5 * stderr), (ratio, stderr)
     assert c["shadow_rays"] > 0      # the floor tries next-event estimation; the slab is in the way
+
+
+def _ggx_weight_integral(view_dirs, alpha, f0, rng, n_samples):
+    """E over pixels and half vectors of the reference's GGX sampling weight (Raytracer.wgsl:271-306), evaluated
+    independently in float64: h ~ D(h) (n.h) around n = +y, l = reflect(-v, h) with the UN-normalised view vector v the
+    reference passes (-ray.direction), weight = F(v.h) G1(n.v) G1(n.l) (v.h) / ((n.v)(n.h)), zero when l dips below the
+    surface.  Returns the mean weight per colour channel."""
+    a2 = alpha * alpha
+    v = view_dirs[rng.integers(0, len(view_dirs), n_samples)]                  # (N, 3), n = +y
+    u = rng.random((n_samples, 2))
+    phi = 2 * np.pi * u[:, 0]
+    ct = np.sqrt(np.maximum(0, (1 - u[:, 1]) / (1 + (a2 - 1) * u[:, 1])))
+    st = np.sqrt(np.maximum(0, 1 - ct * ct))
+    h = np.stack([st * np.cos(phi), ct, st * np.sin(phi)], axis=1)
+    vdh_raw = np.einsum("ij,ij->i", v, h)
+    l = -v + 2 * vdh_raw[:, None] * h
+    ok = l[:, 1] > 0
+    ndv, ndl = np.maximum(v[:, 1], 1e-4), np.maximum(l[:, 1], 1e-4)
+    ndh, vdh = np.maximum(h[:, 1], 1e-4), np.maximum(vdh_raw, 1e-4)
+    g1 = lambda x: 2 * x / (x + np.sqrt(a2 + (1 - a2) * x * x))
+    fres = f0[None, :] + (1 - f0[None, :]) * (np.clip(1 - vdh, 0, 1) ** 5)[:, None]
+    w = np.where(ok, g1(ndv) * g1(ndl) * vdh / (ndv * ndh), 0.0)
+    return (fres * w[:, None]).mean(axis=0)
+
+
+def metal_floor_bridge(roughness):
+    """A GGX floor (metallic 1, f0 = albedo) in the emitting box with the emitters turned away."""
+    le = np.array([2.0, 1.0, 0.5], dtype=np.float32)
+    f0 = np.array([255, 204, 128], dtype=np.float32) / np.float32(255)
+    tris, mats, cols = [], [], []
+    for name, ts in _BOX_FACES.items():
+        for t in ts:
+            t = np.array(t, dtype=np.float32)
+            if name != "floor":
+                t = t[[0, 2, 1]]                       # emitters face outward: the one-sided light pdf is zero
+            tris.append(t)
+            mats.append(1 if name == "floor" else 3)
+            cols.append(f0 if name == "floor" else le)
+    b = bridge_from_triangles(tris, mats, cols)
+    rows = b.mesh_topology.reshape(-1, 20).view(np.float32)
+    rows[rows[:, 7] == 1.0, 8] = 1.0                    # metallic 1: f0 = albedo
+    rows[rows[:, 7] == 1.0, 9] = roughness
+    return b, le, f0
+
+
+@pytest.mark.parametrize("roughness", [0.05, 0.3])
+def test_metal_floor_against_an_independent_integral(W, oracle_lib, roughness):
+    """A GGX floor in the emitting box, emitters turned away so that BSDF sampling is the only strategy: the floor shows
+    Le times the mean sampling weight.  That mean is NOT 1 — the reference's GGX loses energy (12 % at roughness 0.3) and
+    takes an un-normalised view vector — so it is computed here from the formulas of Raytracer.wgsl:236-306 on their own,
+    in float64 numpy, and the oracle's path tracer must land on it: pins sample_ggx, build_onb / reflect and the pickup of
+    emission after a non-specular bounce."""
+    b, le, f0 = metal_floor_bridge(roughness)
+    w = h = 48
+    per_pixel, c = _mean_radiance(W, oracle_lib, b, w, h, 64)
+    assert c["shadow_rays"] == 0
+    cam = b.cameraData.astype(np.float64)
+    eye, ll, hv, vv = cam[0:3], cam[4:7], cam[8:11], cam[12:15]
+    xs, ys = np.meshgrid((np.arange(w) + 0.5) / w, 1.0 - (np.arange(h) + 0.5) / h)
+    d = (ll[None, None, :] + xs[..., None] * hv + ys[..., None] * vv - eye).reshape(-1, 3)
+    weight = _ggx_weight_integral(-d, roughness, f0.astype(np.float64), np.random.default_rng(7), 4_000_000)
+    ratio = per_pixel.mean(axis=(0, 1)) / (weight * le)
+    stderr = per_pixel.std(axis=(0, 1)) / np.sqrt(w * h) / (weight * le)
+    assert (0.85 < weight / f0).all() and (weight / f0 < 1.01).all()
+    assert np.all(np.abs(ratio - 1.0) < np.maximum(5 * stderr, 2.5e-3)), (ratio, stderr, weight)
