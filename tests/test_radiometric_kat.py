@@ -319,3 +319,22 @@ def test_metal_floor_against_an_independent_integral(W, oracle_lib, roughness):
     stderr = per_pixel.std(axis=(0, 1)) / np.sqrt(w * h) / (weight * le)
     assert (0.85 < weight / f0).all() and (weight / f0 < 1.01).all()
     assert np.all(np.abs(ratio - 1.0) < np.maximum(5 * stderr, 2.5e-3)), (ratio, stderr, weight)
+
+
+def test_textured_emitters_scale_the_known_answer(W, oracle_lib):
+    """The emitting box again, every emitter carrying a base-colour texture of constant value 128 / 255: light sampling
+    reads it at the sampled point (Raytracer.wgsl:383-389), a BSDF-sampled hit reads it through the albedo — both must
+    scale by exactly 128 / 255, so the floor shows rho * Le * 128 / 255.  Pins the texel decode (rgba8unorm -> f32), the
+    uv interpolation feeding it and that both strategies see the same emitter."""
+    rho = np.array([128, 204, 51], dtype=np.float32) / np.float32(255)
+    le = np.array([2.0, 1.0, 0.5], dtype=np.float32)
+    b = furnace_floor_bridge(rho, le, True)
+    rows = b.mesh_topology.reshape(-1, 20).view(np.float32)
+    rows[rows[:, 7] == 3.0, 12] = 0.0                   # base-colour texture 0 on the emitters
+    b.uvs = np.random.default_rng(2).uniform(0.05, 0.95, size=len(b.uvs)).astype(np.float32)
+    b.textures = [np.full((1024, 1024, 4), 128, dtype=np.uint8)]
+    per_pixel, c = _mean_radiance(W, oracle_lib, b, 48, 48, 64)
+    expected = rho.astype(np.float64) * le * (128.0 / 255.0)
+    ratio = per_pixel.mean(axis=(0, 1)) / expected
+    stderr = per_pixel.std(axis=(0, 1)) / 48 / expected
+    assert np.all(np.abs(ratio - 1.0) < np.maximum(5 * stderr, 1e-3)), (ratio, stderr)
