@@ -588,12 +588,15 @@ __global__ __launch_bounds__(256, LDS ? 4 : 6) void k_pathtrace_persistent(DevSc
       p.prev_pdf = 0.0f;
       p.specular = true;
       p.depth = 0u;
-      // background pixel (or MAX_DEPTH = 0): the sample is black and ends at once
-      if (!(slot.depth[p.pixel] >= 1.0f) && F.max_depth != 0u) {
-        float4 g = slot.normal_id[p.pixel];
+      // background pixel (or MAX_DEPTH = 0): the sample is black and ends at once.  The three G-buffer words of the
+      // pixel are requested together (they come from HBM: one round trip instead of depth first, then the rest)
+      const float gdepth = slot.depth[p.pixel];
+      const float4 g = slot.normal_id[p.pixel];
+      const uint32_t galbedo = slot.albedo[p.pixel];
+      if (!(gdepth >= 1.0f) && F.max_depth != 0u) {
         p.tri = rt_f2u(g.z);
         p.inst = rt_f2u(g.w);
-        setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
+        setup_surface(S, p, true, g.x, g.y, galbedo);
         alive = true;
       }
     }
