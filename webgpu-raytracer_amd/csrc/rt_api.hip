@@ -51,7 +51,9 @@ struct rt_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   bool wf_overlap = true;
-  int shade_per_cu = 16;         // workgroups per CU of the wavefront shade kernels (MI355RT_SHADE_BLOCKS_PER_CU)
+  int shade_per_cu = 8;          // workgroups per CU of the wavefront shade kernels (MI355RT_SHADE_BLOCKS_PER_CU); swept 4 / 8 /
+                                 // 12 / 16 / 24, shade ms per image: sponza-like 64.6 / 63.9 / 63.9 / 64.3 / 64.7, instanced x1000
+                                 // 35.9 / 36.4 / 36.7 / 37.4 / 38.7 (every wave may leave a partly used queue chunk per launch)
   bool no_lds_staging = false;   // MI355RT_NO_LDS_STAGING=1 (test hook): every record through the global-memory paths
   std::string error;
 
