@@ -9,7 +9,7 @@ Rays     : primary-visibility casts + extension rays + shadow rays actually trac
 N > 1    : `python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed.run, before
            anything in this process touches the GPU); under a launcher (WORLD_SIZE set) it is one of the ranks.
            The image is split into interleaved 8-row stripes across ranks (strong scaling of one image), one RCCL
-           sum-reduce of the float4 accumulation buffer to rank 0 per image.
+           gather of the ranks' compact stripes (1/N of the float4 accumulation buffer each) to rank 0 per image.
 Extra    : "roofline" for the dominant kernel (k_pathtrace_persistent; launch time from HIP events inside the C
            library, on the stream the kernel runs on), "configs" (BASELINE configs 3-5, timed the same way,
            with the roofline of their dominant kernel k_wf_trace) and "cpu_baseline" (the CPU oracle timed on a
@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the lines of BASELINE configs 3-5")
+    ap.add_argument("--no-live-loop", action="store_true", help="skip the per-frame compute(); present() block")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
     return ap.parse_args()
@@ -74,24 +75,26 @@ def launch_ranks(args):
 
 
 def gather_calibration():
-    """Rows of profiles/r02_gather_peak.txt (tools/gather_peak.hip on one MI355X): G lane-steps/s of dependent divergent
-    gathers of one 32-byte record (2 x dwordx4) per step, 40 lanes, 6 workgroups per CU."""
-    path = os.path.join(REPO, "profiles", "r02_gather_peak.txt")
-    out = {}
-    try:
-        for line in open(path):
-            f = line.split()
-            if len(f) >= 6 and f[1:4] == ["2", "40", "6"]:
-                if f[0] == "16KB":
-                    out["l1_resident_Gps"] = float(f[4])
-                elif f[0] == "4MB":
-                    out["l2_resident_Gps"] = float(f[4])
-    except OSError:
-        return None
-    if len(out) != 2:
-        return None
-    out["source"] = "profiles/r02_gather_peak.txt (tools/gather_peak.hip: 32-B records, 40 of 64 lanes, 16 KB / 4 MB table)"
-    return out
+    """Rows of profiles/r03_gather_peak.txt (tools/gather_peak.hip on one MI355X): G lane-steps/s of dependent divergent
+    gathers of one 32-byte record (2 x dwordx4) per step with ALL 64 lanes of every wave active, 6 workgroups per CU — the
+    full-wave rate; the lanes a trace kernel leaves idle are reported as a loss term of their own (lane_utilization)."""
+    for name in ("r03_gather_peak.txt", "r02_gather_peak.txt"):
+        path = os.path.join(REPO, "profiles", name)
+        out = {}
+        try:
+            for line in open(path):
+                f = line.split()
+                if len(f) >= 6 and f[1:4] == ["2", "64", "6"]:
+                    if f[0] == "16KB":
+                        out["l1_resident_Gps"] = float(f[4])
+                    elif f[0] == "4MB":
+                        out["l2_resident_Gps"] = float(f[4])
+        except OSError:
+            continue
+        if len(out) == 2:
+            out["source"] = "profiles/%s (tools/gather_peak.hip: 32-B records, 64 of 64 lanes, 16 KB / 4 MB table)" % name
+            return out
+    return None
 
 
 def cpu_baseline(pkg, bridge, frames):
@@ -159,9 +162,14 @@ def pmc_reference():
     if not os.path.exists(path):
         return {}
     try:
-        return json.load(open(path))
+        ref = json.load(open(path))
     except Exception:
         return {}
+    # counters cannot be read from inside this process: the file names the kernel sources it was collected from, and
+    # figures from other sources are flagged (and the fractions derived from them withheld) instead of quoted
+    import webgpu_raytracer_amd as pkg
+    ref["_stale"] = ref.get("csrc_sha16") != pkg._build.kernel_source_hash()
+    return ref
 
 
 def main():
@@ -240,10 +248,10 @@ def main():
         shard = rtdist.ShardedImage(r, rank, world, device=device, collective_on_device=(backend == "nccl"),
                                     force_collective=force_dist)
 
-        def step():
+        def step(timed=False):
             r.resetAccumulation()
             shard.render(frames, batch=batch)
-            shard.gather(present=True)
+            shard.gather(present=True, timed=timed)
 
         for _ in range(warmup):
             step()
@@ -253,9 +261,10 @@ def main():
         r.kernelTimes()  # drop anything recorded so far
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            step(timed=distributed)
         fence()
         elapsed = time.perf_counter() - t0
+        coll_ms, coll_n = shard.collective_time_ms() if distributed else (0.0, 0)
         ktimes = r.kernelTimes()
         r.setKernelTiming(False)
         counts = r.getCounters()
@@ -270,7 +279,36 @@ def main():
         kc = r.getKernelCounters(1)
         r.setCounting(False)
         return {"bridge": bridge, "renderer": r, "shard": shard, "elapsed": elapsed, "rays": rays_total,
-                "ktimes": ktimes, "kc": kc, "steps": steps}
+                "ktimes": ktimes, "kc": kc, "steps": steps, "collective_ms": coll_ms / coll_n if coll_n else None,
+                "wire_bytes_per_rank": shard.wire_bytes_per_rank() if distributed else 0}
+
+    def live_loop(scene, nframes, depth, width=WIDTH, height=HEIGHT, passes=3):
+        """The reference's live loop (src/main.ts:168-173): compute(frameCount); present() per displayed frame, one
+        dispatch per frame, nothing batched; fire-and-forget like the reference (one fence at the end of a pass)."""
+        bridge = pkg.WorldBridge()
+        bridge.loadScene(scene)
+        r = pkg.WebGPURenderer(local_rank)
+        r.buildPipeline(depth, 1)
+        pkg.upload_scene(r, bridge, width, height)
+
+        def one_pass():
+            r.resetAccumulation()
+            for f in range(1, nframes + 1):
+                r.compute(f)
+                r.present()
+            r.sync()
+
+        one_pass()
+        r.resetCounters()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass()
+        dt = time.perf_counter() - t0
+        c = r.getCounters()
+        r.destroy()
+        rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
+        return {"scene": scene, "workload": "%s %dx%d depth %d: %d x { compute(f); present() }, one dispatch per frame" % (scene, width, height, depth, nframes),
+                "ms_per_frame": round(dt / (passes * nframes) * 1e3, 4), "Mrays_s": round(rays / dt / 1e6, 1), "frames": passes * nframes}
 
     frames = list(range(1, SPP_TOTAL + 1))
     head = run_workload(SCENE, frames, DEPTH, args.steps, args.warmup, args.batch)
@@ -303,7 +341,14 @@ def main():
                 "alg_gather_served_by": "lds (the 8.4 KB scene is staged per workgroup; SURVEY 8d gather bytes never reach HBM)",
                 "alg_hbm_bytes_per_launch": int(stream_bytes),
                 "achieved": None, "frac": None, "traffic": None}
-        if pt.get("lane_instr_per_launch") and launch_ms > 0:
+        stale = bool(ref.get("_stale"))
+        if ref and world == 1:
+            roof["pmc_stale"] = stale
+            roof["pmc_csrc_sha16"] = {"collected_from": ref.get("csrc_sha16"), "this_build": pkg._build.kernel_source_hash()}
+        if stale:
+            roof["pmc_stale_note"] = ("profiles/pmc_reference.json was collected from other kernel sources than this build's: "
+                                      "achieved / frac / traffic (counter-derived) are withheld; re-run tools/make_profiles.sh")
+        if pt.get("lane_instr_per_launch") and launch_ms > 0 and not stale:
             scale = min(args.batch, len(frames)) / float(pt.get("frames_per_launch", 32))
             lane = pt["lane_instr_per_launch"] * scale
             roof["achieved"] = round(lane / (launch_ms * 1e-3) / 1e12, 3)
@@ -338,10 +383,14 @@ def main():
             "config": {"workload": "cornell box 1920x1080, 64 spp as 1 spp x 64 compute() frames (frame_count 1..64, "
                                    "issued as batched dispatches of %d frames), depth 8, one present() per image" % args.batch,
                        "scene": SCENE, "width": WIDTH, "height": HEIGHT, "spp": SPP_TOTAL, "max_depth": DEPTH,
-                       "parallelism": "%d-row stripes x %d ranks + 1 RCCL reduce/image" % (rtdist.STRIPE_ROWS, world) if world > 1 else "1 GPU",
+                       "parallelism": "%d-row stripes x %d ranks + 1 RCCL gather of compact stripes/image" % (rtdist.STRIPE_ROWS, world) if world > 1 else "1 GPU",
                        "frames_per_dispatch": args.batch, "rays_per_image": int(head["rays"] / args.steps)},
             "roofline": roof,
         }
+        if distributed:
+            # pack + gather + unpack on rank 0's stream, per image (events around the collective section)
+            out["collective_ms"] = round(head["collective_ms"], 4) if head["collective_ms"] is not None else None
+            out["collective_bytes_per_rank"] = head["wire_bytes_per_rank"]
         cfgs = []
         for name, scene, nframes, depth, m, cw, ch in extra:
             kt, kc = m["ktimes"], m["kc"]
@@ -356,9 +405,12 @@ def main():
                      "kernel_ms_per_image": {k: round(v["ms"] / m["steps"], 3) for k, v in kt.items() if v["launches"]},
                      "kernel_ms_note": "pathtrace = span of the whole path-trace stage; wf_trace_shadow runs beside wf_trace_ext "
                                        "on a second stream, so those two overlap and do not add up"}
+            if distributed:
+                entry["collective_ms"] = round(m["collective_ms"], 4) if m["collective_ms"] is not None else None
+                entry["collective_bytes_per_rank"] = m["wire_bytes_per_rank"]
             if per_image_trace_ms > 0:
                 gbps = trace_bytes / (per_image_trace_ms * 1e-3) / 1e9
-                rk = ref.get("k_wf_trace", {}).get(scene, {}) if world == 1 else {}
+                rk = ref.get("k_wf_trace", {}).get(scene, {}) if (world == 1 and not ref.get("_stale")) else {}
                 # What the walk is up against (round 2, measured): not HBM and not L2 bandwidth, but the rate at which a CU
                 # takes DEPENDENT lane-divergent 16-byte gathers — tools/gather_peak.hip, 32-byte records (2 x dwordx4 per
                 # step, as a node step), 40 of 64 lanes active as in the trace kernels: every record from the L1 / from L2.
@@ -370,6 +422,9 @@ def main():
                           "frac": round(steps_g / gp["l1_resident_Gps"], 4) if gp else None,
                           "frac_of_l2_resident_rate": round(steps_g / gp["l2_resident_Gps"], 4) if gp else None,
                           "peak_source": gp,
+                          "peak_note": "full-wave rate (64 of 64 lanes active) of dependent divergent 32-byte gathers; the lanes the "
+                                       "kernel leaves idle are a loss term of their own: pmc.*.valu_lane_utilization",
+                          "pmc_stale": bool(ref.get("_stale")) if ref else None,
                           "alg_GBps": round(gbps, 1), "hbm_peak": HBM_PEAK_GBS, "alg_frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4),
                           "l2_peak": L2_PEAK_GBS, "alg_frac_of_l2_peak": round(gbps / L2_PEAK_GBS, 4),
                           "alg_bytes_per_image": int(trace_bytes), "trace_ms_per_image": round(per_image_trace_ms, 3),
@@ -386,6 +441,21 @@ def main():
             cfgs.append(entry)
         if cfgs:
             out["configs"] = cfgs
+        if world == 1 and not args.no_live_loop:
+            # the reference's hot loop as it is written: per-frame dispatch + present, beside the batched cadence
+            ll = []
+            batched = {SCENE: out["ms_per_step"] / SPP_TOTAL}
+            for name, scene, nframes, depth, m, cw, ch in extra:
+                batched[scene] = m["elapsed"] / m["steps"] * 1e3 / nframes
+            for scene, depth in ((SCENE, DEPTH), ("sponza_like", 8)):
+                if scene != SCENE and args.no_extra_configs:
+                    continue
+                e = live_loop(scene, 64, depth)
+                if scene in batched:
+                    e["batched_ms_per_frame"] = round(batched[scene], 4)
+                    e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
+                ll.append(e)
+            out["live_loop"] = ll
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, head["bridge"], frames)
         print(json.dumps(out), flush=True)

@@ -164,8 +164,10 @@ int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
 /* present() reads this caller-owned float4 buffer (width*height*16 bytes, same device) instead of the accumulation
  * buffer; NULL returns to the accumulation buffer.  The sharded renderer reduces the ranks' stripe accumulators into
  * such a display buffer, so the per-rank accumulators stay disjoint and a progressive render can go on after a
- * gather.  Like rt_bind_accum, the binding is dropped by rt_resize, and compute() / present() then fail with
- * RT_ERR_INVALID until the caller binds again (either call, NULL included, acknowledges the new size). */
+ * gather.  Like rt_bind_accum, the binding is dropped by rt_resize; staleness is tracked PER BINDING: compute() and
+ * present() fail with RT_ERR_INVALID until rt_bind_accum is called again (if an accumulator was bound), and present()
+ * also until rt_bind_present_source is called again (if a present source was bound) — NULL included; re-binding one
+ * does not acknowledge the other. */
 int rt_bind_present_source(rt_ctx* ctx, void* device_ptr);
 /* Run every subsequent enqueue on a caller-provided hipStream_t (NULL = context's own stream). */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);

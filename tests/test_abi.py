@@ -74,3 +74,30 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(d, f), errors="ignore").read()
                 assert "rt_oracle" not in text and "oracle_lib" not in text and "oracle/" not in text, \
                     "%s references the oracle" % os.path.join(d, f)
+
+
+def test_hip_runtime_preload_is_guarded(W, tmp_path):
+    """the preload of torch's bundled HIP runtime must not break users who never touch torch.  The ELF reader
+    finds what libmi355rt.so NEEDs and a candidate's SONAME without dlopen; a candidate that cannot be loaded, or whose
+    SONAME is not the one we need, is skipped with a warning instead of raising or silently leaving two runtimes."""
+    import subprocess, sys, os
+    from webgpu_raytracer_amd import renderer as R
+    W._build.build_rt()
+    needed = R._elf_dynamic_strings(W._build.RT_LIB, (1,))[1]
+    assert any(n.startswith("libamdhip64.so") for n in needed)
+    assert R._elf_dynamic_strings(W._build.SCENE_LIB, (14,))[14] in ([], ["libmi355scene.so"])
+    bad = tmp_path / "libamdhip64.so"
+    bad.write_bytes(b"not an ELF file")
+    code = ("import warnings, sys; sys.path.insert(0, %r)\n"
+            "import webgpu_raytracer_amd as W\nfrom webgpu_raytracer_amd import renderer as R\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    R.load_library()\n"
+            "print('NOTE', R.hip_runtime_note)\nprint('WARN', len([x for x in w if issubclass(x.category, RuntimeWarning)]))\n" % REPO)
+    env = dict(os.environ, MI355RT_HIP_RUNTIME=str(bad))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "could not preload" in out.stdout and "WARN 1" in out.stdout
+    env = dict(os.environ, MI355RT_HIP_RUNTIME="system")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "MI355RT_HIP_RUNTIME=system" in out.stdout and "WARN 0" in out.stdout

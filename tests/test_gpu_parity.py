@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 CASES = [
     # scene, w, h, depth, spp, frames
     ("cornell", 128, 128, 4, 1, (1, 2, 3, 4)),          # BASELINE config 1, reduced resolution
+    ("cornell", 512, 512, 4, 1, (1, 2, 3, 4)),          # BASELINE config 1 as it is written: 512x512, 1 spp x 4 frames, depth 4, whole image
     ("cornell", 67, 45, 8, 1, (1, 2)),                   # ragged size: partial 8x8 tiles
     ("cornell", 64, 64, 8, 4, (1, 2)),                   # SPP > 1 inside one dispatch
     ("cornell", 64, 64, 1, 1, (1,)),                     # MAX_DEPTH = 1: no extension rays
@@ -268,9 +269,9 @@ def test_bench_workload_parity_1080p(W, oracle_lib, gpu_renderer):
 
 @pytest.mark.parametrize("scene,w,h,depth,nframes,batch,div", [
     ("viewer_diamond", 1280, 720, 8, 16, 16, 9),     # config 2 at its BASELINE size and frame count (persistent kernel)
-    ("instanced1000", 1920, 1080, 8, 8, 8, 135),     # config 3, full size, 8 of its 64 frames as one batch (wavefront form)
-    ("sponza_like", 1920, 1080, 8, 8, 8, 135),       # config 4
-    ("glass_blob", 3840, 2160, 16, 8, 8, 270),       # config 5 at 4K, depth 16
+    ("instanced1000", 1920, 1080, 8, 64, 32, 135),   # config 3, full size, ALL 64 frames as the two 32-frame batches bench.py times (wavefront form)
+    ("sponza_like", 1920, 1080, 8, 64, 32, 135),     # config 4, likewise
+    ("glass_blob", 3840, 2160, 16, 32, 32, 270),     # config 5 at 4K, depth 16: one 32-frame batch of its 256 frames
 ])
 def test_full_size_oracle_band(W, oracle_lib, gpu_renderer, scene, w, h, depth, nframes, batch, div):
     """BASELINE configs 2-5 at full resolution through the batched dispatch the benchmark uses (auto kernel form: the

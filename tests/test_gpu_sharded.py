@@ -129,7 +129,7 @@ def test_bench_py_gpus_2_from_a_plain_shell(W):
     if renderer.load_library().rt_device_count() < 2:
         env.update(BENCH_ONE_DEVICE="1", BENCH_BACKEND="gloo")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--no-extra-configs", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -137,7 +137,7 @@ def test_bench_py_gpus_2_from_a_plain_shell(W):
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["unit"] == "Mrays/s" and rec["value"] > 0
     # every ray of the image is traced exactly once across the ranks: same count as one GPU (deterministic)
     one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-                          "--no-extra-configs", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop"], env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert rec1["config"]["rays_per_image"] == rec["config"]["rays_per_image"]
@@ -172,5 +172,24 @@ def test_resize_drops_a_bound_accumulator_loudly(W):
     assert r.compute(1) == 0
     r.sync()
     assert float(t2[..., 3].min().item()) == 1.0
+    # staleness is per binding: with both bound, renewing only the accumulator leaves present() refusing to read
+    # the dropped display buffer (it used to fall back to the internal accumulator silently)
+    d2 = torch.zeros((48, 80, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    r.bindPresentSource(d2.data_ptr())
+    r.updateScreenSize(64, 48)
+    t3 = torch.zeros((48, 64, 4), dtype=torch.float32, device="cuda:0")
+    d3 = torch.zeros((48, 64, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    r.bindAccum(t3.data_ptr())
+    b.updateCamera(64, 48)
+    r.updateSceneUniforms(b.cameraData, 0, b.lightCount)
+    assert r.compute(1) == 0
+    with pytest.raises(W.RendererError, match="rt_bind_present_source again"):
+        r.present()
+    r.bindPresentSource(d3.data_ptr())
+    assert r.present() == 0
+    r.sync()
+    r.bindPresentSource(0)
     r.bindAccum(0)
     r.destroy()

@@ -8,7 +8,11 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import webgpu_raytracer_amd as _W  # noqa: E402  (the hash of the kernel sources the counters were collected from)
+
 d, commit = sys.argv[1], sys.argv[2]
+TAG = os.environ.get("RTAG", "r03")
 out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_reference.json")
 
 
@@ -24,13 +28,14 @@ def kernel(tab, prefix):
     return {}
 
 
-ref = {"source": "rocprofv3 --pmc passes of tools/make_profiles_r02.sh (one counter set per run), collected at commit %s; "
-                 "per-kernel averages in profiles/r02_*_pmc.json" % commit,
+ref = {"source": "rocprofv3 --pmc passes of tools/make_profiles.sh (one counter set per run), collected at commit %s; "
+                 "per-kernel averages in profiles/%s_*_pmc.json" % (commit, TAG),
+       "csrc_sha16": _W._build.kernel_source_hash(),
        "notes": {"FETCH_SIZE": "KB; doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B) - calibrated for wide "
                                "coalesced reads only, so both the raw and the doubled figure are given",
                  "WRITE_SIZE": "KB, exact for 16-B-per-lane stores",
                  "lane_instr": "SQ_THREAD_CYCLES_VALU = active lanes summed over the VALU instructions of the launch"}}
-c = load("r02_cornell_pmc.json")
+c = load(TAG + "_cornell_pmc.json")
 pt = kernel(c, "k_pathtrace_persistent")
 if pt:
     lane = pt.get("SQ_THREAD_CYCLES_VALU")
@@ -50,22 +55,24 @@ if pt:
         entry["fetch_bytes_doubled"] = pt["FETCH_SIZE"] * 2048.0
         entry["write_bytes"] = pt["WRITE_SIZE"] * 1024.0
         entry["hbm_bytes_per_launch"] = pt["FETCH_SIZE"] * 2048.0 + pt["WRITE_SIZE"] * 1024.0
-    clk = load("r02_clock_check.json")
+    clk = load(TAG + "_clock_check.json")
     if clk:
         entry["effective_clock_GHz"] = clk.get("in_kernel_clock_GHz_median")
         entry["cycles_per_workgroup"] = clk.get("cycles_per_workgroup_median")
-    vp = os.path.join(d, "r02_valu_peak.txt")
+    vp = os.path.join(d, TAG + "_valu_peak.txt")
     if os.path.exists(vp):
         best = max(float(m) for m in re.findall(r"([0-9.]+) T lane-instr/s", open(vp).read()))
         entry["measured_issue_peak_Tlane"] = best
     ref["k_pathtrace_persistent"] = entry
 tr = {}
+# scene -> (frames in the profiled batch, frames of one image of the BASELINE config)
+PROFILED = {"sponza_like": (32, 64), "instanced1000": (32, 64), "glass_blob": (8, 256)}
 for scene in ("sponza_like", "instanced1000", "glass_blob"):
-    t = load("r02_%s_pmc.json" % scene)
+    t = load(TAG + "_%s_pmc.json" % scene)
     rows = {k: v for k, v in t.items() if "k_wf_trace" in k}
     if not rows:
         continue
-    e = {"frames_per_image_profiled": 32, "kernels": {}}
+    e = {"frames_per_image_profiled": PROFILED[scene][0], "frames_per_image": PROFILED[scene][1], "kernels": {}}
     hbm = 0.0
     for k, v in rows.items():
         name = "any_hit" if "k_wf_trace<true" in k else "closest_hit"
@@ -91,7 +98,7 @@ for scene in ("sponza_like", "instanced1000", "glass_blob"):
                 ke["valu_lane_utilization"] = round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
         e["kernels"][name] = ke
     if hbm:
-        e["hbm_bytes_per_image"] = hbm * 2.0   # profiled on 32 of the image's 64 frames
+        e["hbm_bytes_per_image"] = hbm * PROFILED[scene][1] / PROFILED[scene][0]   # one profiled batch scaled to the image's frames
     tr[scene] = e
 if tr:
     ref["k_wf_trace"] = tr

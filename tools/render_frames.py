@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--rank", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.rank is None and args.gpus > 1:
-        # one fresh process per GPU, started before anything here touches the GPU
+        # build once here (compile only: no GPU is touched), so that the ranks never write the libraries concurrently;
+        # then one fresh process per GPU, started before anything here touches the GPU
+        import webgpu_raytracer_amd as W
+        W._build.build_all()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--rank", str(r)])
                  for r in range(args.gpus)]
         sys.exit(max(p.wait() for p in procs))

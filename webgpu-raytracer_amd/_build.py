@@ -7,6 +7,8 @@
 
 Outputs are git-ignored (*.so) but travel to the GPU box with the gpurun snapshot.
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -35,6 +37,31 @@ HIP_FLAGS = [
 ]
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout (ranks of one job may all find a library stale at once)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _compile(cmd, target):
+    """Run a compiler command whose output (`-o <target>`) goes to a temporary name first and is renamed into place:
+    a process that dlopens the library meanwhile sees the old file or the new one, never a partial one."""
+    tmp = "%s.tmp.%d" % (target, os.getpid())
+    cmd = [tmp if a == target else a for a in cmd]
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return False
@@ -55,14 +82,31 @@ def _headers():
     return _glob_sources(INCLUDE, (".h",))
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over every source the HIP library is built from (csrc/** and include/*.h, path-sorted,
+    names included).  profiles/pmc_reference.json records it at collection time; bench.py recomputes it and flags counter
+    figures collected from other kernels as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    files = _glob_sources(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _headers()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, REPO_DIR).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def build_scene(force=False):
     src = os.path.join(CSRC, "scene", "scene_compiler.cpp")
     deps = [src] + _headers()
     if not force and _newer(SCENE_LIB, deps):
         return SCENE_LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", SCENE_LIB, src]
-    subprocess.run(cmd, check=True)
+    with _build_lock():
+        if not force and _newer(SCENE_LIB, deps):   # another process built it while we waited
+            return SCENE_LIB
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", SCENE_LIB, src]
+        _compile(cmd, SCENE_LIB)
     return SCENE_LIB
 
 
@@ -71,9 +115,11 @@ def build_tex(force=False):
     deps = [src] + _headers()
     if not force and _newer(TEX_LIB, deps):
         return TEX_LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", TEX_LIB, src]
-    subprocess.run(cmd, check=True)
+    with _build_lock():
+        if not force and _newer(TEX_LIB, deps):
+            return TEX_LIB
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", TEX_LIB, src]
+        _compile(cmd, TEX_LIB)
     return TEX_LIB
 
 
@@ -84,9 +130,11 @@ def build_rt(force=False, extra_flags=()):
         return RT_LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: the HIP renderer cannot be built" % HIPCC)
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-o", RT_LIB, src]
-    subprocess.run(cmd, check=True)
+    with _build_lock():
+        if not force and _newer(RT_LIB, deps):
+            return RT_LIB
+        cmd = [HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-o", RT_LIB, src]
+        _compile(cmd, RT_LIB)
     return RT_LIB
 
 
@@ -102,7 +150,8 @@ def build_node_addon(force=False):
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I", "/usr/include/node", "-I", INCLUDE,
            "-o", NODE_ADDON, src, "-L", LIB_DIR, "-lmi355rt", "-lmi355scene", "-lmi355tex",
            "-Wl,-rpath,$ORIGIN/../lib"]
-    subprocess.run(cmd, check=True)
+    with _build_lock():
+        _compile(cmd, NODE_ADDON)
     return NODE_ADDON
 
 

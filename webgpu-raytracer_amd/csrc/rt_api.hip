@@ -81,7 +81,8 @@ struct rt_ctx {
   DeviceBuffer accum, render_target, g_normal, g_depth, history[2], counters;
   void* external_accum = nullptr;
   void* present_source = nullptr;   // rt_bind_present_source: present() reads this instead of the accumulation buffer
-  bool external_stale = false;      // a bound buffer was sized for the screen before the last rt_resize
+  bool accum_stale = false;         // rt_bind_accum's buffer was sized for the screen before the last rt_resize ...
+  bool present_stale = false;       // ... and so was rt_bind_present_source's: each is cleared only by its own bind call
   int history_index = 0;
 
   // uniforms + host state (ResourceManager fields)
@@ -543,7 +544,8 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   // A bound accumulation / present buffer was sized for the old screen: it is dropped, and until the caller binds
   // again (rt_bind_accum / rt_bind_present_source, NULL included) compute() and present() refuse to run instead of
   // silently rendering into the internal buffer while the caller keeps reducing its stale one.
-  if (c->external_accum || c->present_source) c->external_stale = true;
+  if (c->external_accum) c->accum_stale = true;
+  if (c->present_source) c->present_stale = true;
   c->external_accum = nullptr;
   c->present_source = nullptr;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1095,7 +1097,7 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     slots[i].pad2 = 0;
   }
   if (!scene_ready(c)) return RT_SKIPPED;
-  if (c->external_stale)
+  if (c->accum_stale)
     return fail(c, RT_ERR_INVALID, "the bound accumulation buffer was dropped by rt_resize: call rt_bind_accum again");
   HIP_TRY(c, hipSetDevice(c->device));
   // Host-side shape checks before any kernel indexes these buffers.
@@ -1270,8 +1272,10 @@ int rt_compute_batch(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
 int rt_present(rt_ctx* c) {
   if (!c) return RT_ERR_INVALID;
   if (!c->width || !c->render_target.ptr || !c->accum.ptr) return RT_SKIPPED;  // PostProcessPass.ts:32-38
-  if (c->external_stale)
+  if (c->accum_stale)
     return fail(c, RT_ERR_INVALID, "the bound accumulation buffer was dropped by rt_resize: call rt_bind_accum again");
+  if (c->present_stale)
+    return fail(c, RT_ERR_INVALID, "the bound present source was dropped by rt_resize: call rt_bind_present_source again");
   HIP_TRY(c, hipSetDevice(c->device));
   DevPost P;
   P.accum = c->present_source ? (const float4*)c->present_source : accum_ptr(c);
@@ -1402,7 +1406,7 @@ int rt_bind_accum(rt_ctx* c, void* device_ptr) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->external_accum = device_ptr;
-  c->external_stale = false;
+  c->accum_stale = false;
   return RT_OK;
 }
 int rt_bind_present_source(rt_ctx* c, void* device_ptr) {
@@ -1410,7 +1414,7 @@ int rt_bind_present_source(rt_ctx* c, void* device_ptr) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->present_source = device_ptr;
-  c->external_stale = false;
+  c->present_stale = false;
   return RT_OK;
 }
 int rt_set_stream(rt_ctx* c, void* hip_stream) {

@@ -725,13 +725,26 @@ void make_texture(std::vector<uint8_t>& out, int kind, uint32_t seed) {
 }
 
 // Tessellated helpers for the large synthetic scenes: smooth normals, real UVs.
+// jitter > 0: every interior grid vertex is moved ON the surface by up to +-jitter cells in u and v (LCG, seeded per
+// patch).  A regular grid is the worst case for the reference's builder: blas.rs:106 picks axis y whenever extent.y >
+// extent.x, a one-cell-high strip of a regular grid has all its centroids at ONE height, nothing can be split and the
+// strip becomes a fallback leaf whose 3-bit count overflows (blas.rs:111-115) — a third of the regular sponza-like mesh
+// was unreachable for every ray.  Real meshes are not regular grids; with jittered vertices the centroids differ and
+// the builder (unchanged) splits them.
 void add_grid_patch(Geometry& g, int nu, int nv, V3 (*fn)(float, float, const float*), const float* prm, V3 color,
-                    uint32_t mat, float metallic, float roughness, float ior, const float tex[4], float uv_scale) {
+                    uint32_t mat, float metallic, float roughness, float ior, const float tex[4], float uv_scale,
+                    float jitter = 0.0f, uint32_t jitter_seed = 0u) {
   uint32_t start = (uint32_t)g.positions.size();
   const float eps = 1e-3f;
+  Lcg jr(jitter_seed * 2654435761u + 12345u);
   for (int j = 0; j <= nv; j++)
     for (int i = 0; i <= nu; i++) {
       float u = (float)i / (float)nu, v = (float)j / (float)nv;
+      if (jitter > 0.0f) {
+        const float du = (jr.unit() * 2.0f - 1.0f) * jitter / (float)nu, dv = (jr.unit() * 2.0f - 1.0f) * jitter / (float)nv;
+        if (i > 0 && i < nu) u += du;   // the border (and the seam of a closed patch) stays where the neighbours expect it
+        if (j > 0 && j < nv) v += dv;
+      }
       V3 p = fn(u, v, prm);
       V3 du = fn(u + eps, v, prm) - fn(u - eps, v, prm);
       V3 dv = fn(u, v + eps, prm) - fn(u, v - eps, prm);
@@ -792,6 +805,7 @@ V3 fn_torus_knot(float u, float v, const float* p) {  // (2,3) torus knot tube: 
 SceneData scene_sponza_like() {
   SceneData sd;
   Geometry g;
+  const float SPONZA_JITTER = 0.40f;   // cells; see add_grid_patch
   sd.textures_rgba.resize(8);
   for (int i = 0; i < 8; i++) make_texture(sd.textures_rgba[i], i, 1u + (uint32_t)i);
   const float t_floor[4] = {0, -1, -1, -1}, t_wall[4] = {1, -1, -1, -1}, t_col[4] = {2, 3, -1, -1},
@@ -799,17 +813,17 @@ SceneData scene_sponza_like() {
   // hall: x in [-6,6], y in [0,5], z in [-2.5,2.5]
   {
     const float fl[6] = {-6, 6, -2.5f, 2.5f, 0, 1};
-    add_grid_patch(g, 128, 128, fn_plane_xz, fl, v3(0.8f, 0.8f, 0.8f), METAL, 0.6f, 0.35f, 1.5f, t_metal, 6.0f);
+    add_grid_patch(g, 128, 128, fn_plane_xz, fl, v3(0.8f, 0.8f, 0.8f), METAL, 0.6f, 0.35f, 1.5f, t_metal, 6.0f, SPONZA_JITTER, 1u);
     const float ce[6] = {-6, 6, -2.5f, 2.5f, 5, 0};
-    add_grid_patch(g, 96, 96, fn_plane_xz, ce, v3(0.7f, 0.7f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_ceil, 4.0f);
+    add_grid_patch(g, 96, 96, fn_plane_xz, ce, v3(0.7f, 0.7f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_ceil, 4.0f, SPONZA_JITTER, 2u);
     const float bk[6] = {-6, 6, 0, 5, 2.5f, 1};
-    add_grid_patch(g, 128, 64, fn_plane_xy, bk, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f);
+    add_grid_patch(g, 128, 64, fn_plane_xy, bk, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f, SPONZA_JITTER, 3u);
     const float fr[6] = {-6, 6, 0, 5, -2.5f, 0};
-    add_grid_patch(g, 128, 64, fn_plane_xy, fr, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f);
+    add_grid_patch(g, 128, 64, fn_plane_xy, fr, v3(0.75f, 0.7f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_wall, 5.0f, SPONZA_JITTER, 4u);
     const float lf[6] = {-2.5f, 2.5f, 0, 5, -6, 0};
-    add_grid_patch(g, 64, 64, fn_plane_zy, lf, v3(0.65f, 0.3f, 0.25f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f);
+    add_grid_patch(g, 64, 64, fn_plane_zy, lf, v3(0.65f, 0.3f, 0.25f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f, SPONZA_JITTER, 5u);
     const float rt[6] = {-2.5f, 2.5f, 0, 5, 6, 1};
-    add_grid_patch(g, 64, 64, fn_plane_zy, rt, v3(0.3f, 0.45f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f);
+    add_grid_patch(g, 64, 64, fn_plane_zy, rt, v3(0.3f, 0.45f, 0.65f), LAMBERTIAN, 0, 1, 1.5f, t_floor, 3.0f, SPONZA_JITTER, 6u);
   }
   // two colonnades of 8 columns + arches between neighbours
   for (int side = 0; side < 2; side++) {
@@ -817,10 +831,10 @@ SceneData scene_sponza_like() {
     for (int k = 0; k < 8; k++) {
       float x = -5.25f + 1.5f * (float)k;
       const float cy[5] = {x, z, 0.18f, 0.0f, 3.0f};
-      add_grid_patch(g, 64, 48, fn_cylinder, cy, v3(0.85f, 0.8f, 0.7f), METAL, 1.0f, 0.5f, 1.5f, t_col, 2.0f);
+      add_grid_patch(g, 32, 96, fn_cylinder, cy, v3(0.85f, 0.8f, 0.7f), METAL, 1.0f, 0.5f, 1.5f, t_col, 2.0f, SPONZA_JITTER, 16u + 2u * (uint32_t)(side * 8 + k));
       if (k < 7) {
         const float ar[5] = {x, x + 1.5f, z, 3.0f, 0.14f};
-        add_grid_patch(g, 64, 36, fn_arch, ar, v3(0.8f, 0.75f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_arch, 2.0f);
+        add_grid_patch(g, 64, 36, fn_arch, ar, v3(0.8f, 0.75f, 0.7f), LAMBERTIAN, 0, 1, 1.5f, t_arch, 2.0f, SPONZA_JITTER, 17u + 2u * (uint32_t)(side * 8 + k));
       }
     }
   }

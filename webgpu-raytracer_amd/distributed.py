@@ -4,15 +4,17 @@ The reference distributes *video frame ranges* across browsers over WebRTC
 (src/distributed/DistributedHost.ts:90-140) and reduces nothing (that unit is `recorder.FrameLoop`'s
 `frame_range`).  On one MI355X node the natural unit is the pixel: every pixel is independent given
 (pixel_idx, frame_count) (Raytracer.wgsl:794-798), so each rank path-traces an interleaved set of 8-row
-stripes of the same image into its own zero-initialised full-size STRIPE accumulator, and ONE sum-reduce of
-the float4 buffer to rank 0 (RCCL over xGMI: 33 MB at 1080p) assembles the image.  Disjoint stripes + zeros
-=> bitwise identical to the single-GPU image.  The post pass needs a 2-pixel halo and the history texture,
-so it runs on rank 0 only.
+stripes of the same image into its own full-size STRIPE accumulator (it only ever writes the rows it owns), and ONE
+collective per image assembles the picture on rank 0: a GATHER of COMPACT stripes — every rank packs the rows it owns
+(1/N of the image: 16.6 MB per rank at 4K over 8 ranks instead of the 133 MB a full-frame sum-reduce moved) and rank 0
+copies each rank's rows to their place in its display buffer.  Pure copies, no floating-point addition anywhere
+=> bitwise identical to the single-GPU image.  The post pass needs a 2-pixel halo and the history texture, so it runs
+on rank 0 only.
 
-The reduce is OUT OF PLACE: every rank copies its stripe accumulator into a display buffer and the display
-buffers are reduced; rank 0 presents from its display buffer (rt_bind_present_source).  The stripe accumulators
-are never touched by a gather, so a progressive render may go on after it (render -> gather -> render -> gather,
-the live loop's present-every-frame pattern) and every gather yields the single-GPU image of that moment.
+The gather is OUT OF PLACE: the stripe accumulators are only read (packed into a send buffer); rank 0 presents from
+its display buffer (rt_bind_present_source).  A progressive render may therefore go on after a gather (render ->
+gather -> render -> gather, the live loop's present-every-frame pattern) and every gather yields the single-GPU image
+of that moment.
 
 `ShardedImage` works with any object exposing the WebGPURenderer surface.  On GPUs (`device` given) both buffers
 are torch tensors and the renderer, the copy and the collective all run on ONE torch side stream, so they are
@@ -51,6 +53,7 @@ class ShardedImage:
         with torch.cuda.stream(self.stream):
             self.stripe = torch.zeros((r.height, r.width, 4), dtype=torch.float32, device=self.device)
             self.display = torch.zeros((r.height, r.width, 4), dtype=torch.float32, device=self.device)
+        self._plan_key = None
         self.stream.synchronize()              # the zero fills are done before the renderer is pointed at the memory
         r.setStream(self.stream.cuda_stream)
         r.bindAccum(self.stripe.data_ptr())
@@ -61,6 +64,38 @@ class ShardedImage:
 
     def owned_rows(self, height):
         return (np.arange(height) // self.stripe_rows) % self.world == self.rank
+
+    def rows_of(self, rank, height):
+        """Row indices (ascending) of the image that `rank` owns."""
+        return np.nonzero((np.arange(height) // self.stripe_rows) % self.world == rank)[0]
+
+    def max_rows(self, height):
+        """Rows of the largest share: the gather moves equal-sized (padded) blocks."""
+        return max(len(self.rows_of(k, height)) for k in range(self.world))
+
+    def wire_bytes_per_rank(self):
+        """Bytes one rank contributes to one gather (the padded compact block)."""
+        return self.max_rows(self.r.height) * self.r.width * 16
+
+    def _plan(self):
+        """Index tensors and transfer buffers of the compact gather for the renderer's current size (device path)."""
+        import torch
+        h, w = self.r.height, self.r.width
+        key = (h, w, self.world, self.rank)
+        if getattr(self, "_plan_key", None) == key:
+            return
+        mr = self.max_rows(h)
+        with torch.cuda.stream(self.stream):
+            self._own_idx = torch.from_numpy(self.rows_of(self.rank, h)).to(self.device)
+            self._send = torch.zeros((mr, w, 4), dtype=torch.float32, device=self.device)
+            if self.rank == 0:
+                self._recv = [torch.zeros((mr, w, 4), dtype=torch.float32, device=self.device) for _ in range(self.world)]
+                self._idx = [torch.from_numpy(self.rows_of(k, h)).to(self.device) for k in range(self.world)]
+            else:
+                self._recv = self._idx = None
+        self._plan_key = key
+        self.collective_ms = 0.0
+        self._coll_events = []
 
     # ------------------------------------------------------------------ render / gather
     def render(self, frames, batch=1):
@@ -75,33 +110,66 @@ class ShardedImage:
             for f in frames:
                 self.r.compute(f)
 
-    def gather(self, present=True):
-        """Sum the per-rank stripe accumulators into rank 0's display buffer; rank 0 then runs the post pass on it.
-        The stripe accumulators are left as they are."""
+    def gather(self, present=True, timed=False):
+        """Assemble the image on rank 0 from the ranks' compact stripes (one gather); rank 0 then runs the post pass on
+        its display buffer.  The stripe accumulators are left as they are.  timed: bracket the pack + collective +
+        unpack with events on the stream (collective_time_ms() reads them)."""
         if self._sharded():
             import torch
             import torch.distributed as dist
             if self.on_device:
+                self._plan()
                 with torch.cuda.stream(self.stream):
-                    # renderer kernels, this copy and the collective are ordered by the one side stream
-                    self.display.copy_(self.stripe, non_blocking=True)
-                    dist.reduce(self.display, dst=0, op=dist.ReduceOp.SUM)
+                    # renderer kernels, the packing copy, the collective and the unpacking copies are ordered by the one
+                    # side stream: no host synchronisation anywhere
+                    if timed:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(self.stream)
+                    n_own = self._own_idx.numel()
+                    torch.index_select(self.stripe, 0, self._own_idx, out=self._send[:n_own])
+                    dist.gather(self._send, gather_list=self._recv, dst=0)
+                    if self.rank == 0:
+                        for k in range(self.world):
+                            self.display.index_copy_(0, self._idx[k], self._recv[k][:self._idx[k].numel()])
+                    if timed:
+                        e1.record(self.stream)
+                        self._coll_events.append((e0, e1))
             else:
                 self.r.sync()
-                own = self.r.readAccum()
-                t = torch.from_numpy(own.copy())   # gloo may use a non-root input as scratch: never hand it the accumulator
-                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                h = self.r.height
+                own_full = self.r.readAccum()
+                rows = self.rows_of(self.rank, h)
+                block = np.zeros((self.max_rows(h),) + own_full.shape[1:], dtype=np.float32)
+                block[:len(rows)] = own_full[rows]
+                t = torch.from_numpy(block)
+                recv = [torch.zeros_like(t) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(t, gather_list=recv, dst=0)
                 if self.rank == 0:
-                    self._host_image = t.numpy()
+                    img = np.zeros_like(own_full)
+                    for k in range(self.world):
+                        rk = self.rows_of(k, h)
+                        img[rk] = recv[k].numpy()[:len(rk)]
+                    self._host_image = img
                     if present:
-                        # the host path has no second device buffer: show the sum, then put the stripes back
+                        # the host path has no second device buffer: show the assembled image, then put the stripes back
                         self.r.writeAccum(self._host_image)
                         self.r.present()
                         self.r.sync()
-                        self.r.writeAccum(own)
+                        self.r.writeAccum(own_full)
                 return
         if present and self.rank == 0:
             self.r.present()
+
+    def collective_time_ms(self):
+        """Sum of the timed gathers' stream durations since the last call, and their count."""
+        ev = getattr(self, "_coll_events", [])
+        if not ev:
+            return 0.0, 0
+        self.stream.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev)
+        n = len(ev)
+        self._coll_events = []
+        return ms, n
 
     def read_image(self):
         """Rank 0: the assembled float4 accumulation image of the last gather() as (H, W, 4) float32."""

@@ -23,28 +23,108 @@ class RendererError(RuntimeError):
 
 
 _hip_runtime = None
+hip_runtime_note = None   # what the last load_library() decided about the HIP runtime, for diagnostics
 
 
-def _preload_hip_runtime():
+def _elf_dynamic_strings(path, want_tags):
+    """DT_NEEDED (1) / DT_SONAME (14) strings of a 64-bit little-endian ELF, read straight from the file (no tool, no dlopen)."""
+    import struct
+    out = {t: [] for t in want_tags}
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        return out
+    e_shoff, = struct.unpack_from("<Q", data, 0x28)
+    e_shentsize, e_shnum = struct.unpack_from("<HH", data, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", data, e_shoff + i * e_shentsize) for i in range(e_shnum)]
+    for sh in secs:
+        if sh[1] != 6:          # SHT_DYNAMIC
+            continue
+        stroff = secs[sh[6]][4]  # sh_link -> .dynstr
+        for off in range(sh[4], sh[4] + sh[5], 16):
+            tag, val = struct.unpack_from("<qQ", data, off)
+            if tag == 0:
+                break
+            if tag in out:
+                end = data.index(b"\0", stroff + val)
+                out[tag].append(data[stroff + val:end].decode())
+    return out
+
+
+def mapped_hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps): more than one = two runtimes."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as maps:
+            for line in maps:
+                f = line.split()
+                if len(f) >= 6 and os.path.basename(f[5]).startswith("libamdhip64.so"):
+                    found.add(os.path.realpath(f[5]))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def _preload_hip_runtime(rt_lib_path):
     """ONE HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it
     as `libamdhip64.so`; libmi355rt.so asks for `libamdhip64.so.7` (RUNPATH /opt/rocm).  The loader matches by the
     requested name, so whichever came second used to get a second copy of the runtime: `import torch` after the renderer
     then found "No HIP GPUs", and stream handles or events of one copy meant nothing to the other.  When torch is installed
     its copy is therefore loaded first, globally — our NEEDED entry matches its SONAME, torch's later request resolves to
-    the same file — and the renderer, torch and RCCL share one runtime whatever the import order.  Without torch (or with
-    MI355RT_HIP_RUNTIME=<path to a libamdhip64.so>) the system runtime of the RUNPATH is used.  No GPU is touched here."""
-    global _hip_runtime
+    the same file — and the renderer, torch and RCCL share one runtime whatever the import order.
+
+    Guarded (a user who never touches torch must not be broken by it): the candidate is used only when its SONAME is what
+    libmi355rt.so NEEDs (else the preload could not satisfy our request and the two-runtime bug would come back silently:
+    warned instead); a candidate that fails to load (missing comgr / hsa dependencies, CPU-only torch layout) is skipped
+    with a warning and the RUNPATH runtime is used.  MI355RT_HIP_RUNTIME=<path> names the runtime explicitly,
+    MI355RT_HIP_RUNTIME=system never preloads.  No GPU is touched here."""
+    global _hip_runtime, hip_runtime_note
     if _hip_runtime is not None:
         return
+    import warnings
+    _hip_runtime = False
     path = os.environ.get("MI355RT_HIP_RUNTIME")
+    if path == "system":
+        hip_runtime_note = "system runtime of the RUNPATH (MI355RT_HIP_RUNTIME=system)"
+        return
+    already = mapped_hip_runtimes()
+    if already and not path:
+        hip_runtime_note = "a HIP runtime is already mapped (%s): nothing preloaded" % ", ".join(already)
+        return
+    explicit = bool(path)
     if not path:
         import importlib.util
-        spec = importlib.util.find_spec("torch")
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
         if spec is not None and spec.submodule_search_locations:
             cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
             if os.path.exists(cand):
                 path = cand
-    _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL) if path else False
+    if not path:
+        hip_runtime_note = "system runtime of the RUNPATH (no torch-bundled libamdhip64.so found)"
+        return
+    try:
+        needed = [n for n in _elf_dynamic_strings(rt_lib_path, (1,))[1] if n.startswith("libamdhip64.so")]
+        soname = _elf_dynamic_strings(path, (14,))[14]
+    except (OSError, ValueError, IndexError, KeyError) as e:
+        needed, soname = [], []
+        warnings.warn("mi355rt: cannot read the ELF dynamic section for the HIP runtime check (%s)" % e, RuntimeWarning)
+    if needed and soname and soname[0] not in needed:
+        hip_runtime_note = "%s has SONAME %s but libmi355rt.so needs %s: not preloaded" % (path, soname[0], needed[0])
+        warnings.warn("mi355rt: " + hip_runtime_note + " — torch and the renderer will use DIFFERENT HIP runtimes in this "
+                      "process (streams / events cannot be shared; set MI355RT_HIP_RUNTIME to a matching libamdhip64.so)",
+                      RuntimeWarning)
+        return
+    try:
+        _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        hip_runtime_note = "preloaded %s%s" % (path, "" if explicit else " (torch's bundled runtime)")
+    except OSError as e:
+        _hip_runtime = False
+        hip_runtime_note = "could not preload %s (%s): system runtime of the RUNPATH" % (path, e)
+        warnings.warn("mi355rt: " + hip_runtime_note + (" — a later `import torch` would map a second HIP runtime"
+                                                         if not explicit else ""), RuntimeWarning)
 
 
 def load_library(path=None):
@@ -57,8 +137,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise RendererError(
             "HIP renderer library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
-    _preload_hip_runtime()
+    _preload_hip_runtime(path)
     L = ctypes.CDLL(path)
+    maps = mapped_hip_runtimes()
+    if len(maps) > 1:   # the two-runtime state the preload exists to prevent: say so instead of failing later in odd ways
+        import warnings
+        warnings.warn("mi355rt: %d HIP runtimes are mapped in this process (%s); handles of one mean nothing to the other"
+                      % (len(maps), ", ".join(maps)), RuntimeWarning)
     vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
     sigs = {
         "rt_create": (vp, [i32]), "rt_destroy": (None, [vp]), "rt_last_error": (ctypes.c_char_p, [vp]),
