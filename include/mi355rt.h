@@ -195,6 +195,10 @@ int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
  * the original-index -> new-index table, and the per-instance BLAS roots (any pointer may be NULL).  Returns the node count. */
 int rt_debug_read_traversal_nodes(rt_ctx* ctx, float* tnodes_out, uint32_t* new_index_out, uint32_t* inst_root_out,
                                   uint32_t cap_nodes);
+/* Debug / test read-back of the child-pair records the trace kernels walk (csrc/k_pairs.hip.h): pairs_out receives
+ * 16 floats per inner node, root_rec_out 8 floats per instance plus 8 for the TLAS root (either may be NULL).  Returns the
+ * number of pair records, or < 0 (cap_pairs too small, no scene). */
+int rt_debug_read_pairs(rt_ctx* ctx, float* pairs_out, float* root_rec_out, uint32_t cap_pairs);
 /* Diagnostic build (-DRT_TRACE_STAMPS) only: s_memtime cycles the waves of k_wf_trace spent in its three sections,
  * summed over all launches since the last reset: out16[queue][k], queue 0 = closest hit, 1 = any hit; k = 0..2 cycles in
  * {retire / pull, node step, triangle flush}, 3..5 how often each did work, 6 waves, 7 loop trips.  Returns 1 in the

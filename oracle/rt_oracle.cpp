@@ -1286,6 +1286,31 @@ void oracle_trace_vs_brute_force(oracle_ctx* c, const float* rays, uint32_t n, f
   o.stripe_rows = sr;
 }
 
+// Single rays through the restated traversal, with each ray's own counters (tests/test_pairwalk_model.py checks the
+// child-pair walk of the HIP kernels against it ray by ray).  rays: n x 8 f32 {o.xyz, t_min, d.xyz, t_max};
+// any = 0: intersect_tlas (Raytracer.wgsl:496-528) -> out n x 4 f32 {t, tri, inst, 0};
+// any = 1: intersect_tlas_shadow (:566-600) -> {0, 0, 0, occluded}.  counts: n x 2 u64 {nodes_visited, tris_tested}.
+void oracle_trace_rays(oracle_ctx* c, const float* rays, uint32_t n, int any, float* out, uint64_t* counts) {
+  Oracle& o = c->o;
+  for (uint32_t k = 0; k < n; k++) {
+    const float* q = rays + (size_t)k * 8;
+    Ray r = make_ray(rt3_make(q[0], q[1], q[2]), rt3_make(q[4], q[5], q[6]));
+    Counters cn;
+    float* w = out + (size_t)k * 4;
+    w[0] = w[1] = w[2] = w[3] = 0.0f;
+    if (any) {
+      w[3] = o.intersect_tlas_shadow(r, q[3], q[7], cn) ? 1.0f : 0.0f;
+    } else {
+      HitResult h = o.intersect_tlas(r, q[3], q[7], cn);
+      w[0] = h.t;
+      w[1] = h.tri_idx;
+      w[2] = (float)h.inst_idx;
+    }
+    counts[2 * (size_t)k] = cn.nodes_visited;
+    counts[2 * (size_t)k + 1] = cn.tris_tested;
+  }
+}
+
 // per-node visit counts of the following compute() calls (n_nodes u32, zeroed here); NULL switches the histogram off
 void oracle_set_node_histogram(oracle_ctx* c, uint32_t* hist) {
   c->o.node_hist = reinterpret_cast<std::atomic<uint32_t>*>(hist);

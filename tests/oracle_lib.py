@@ -45,6 +45,7 @@ def lib():
             "oracle_read_history": [vp, vp], "oracle_read_uniforms": [vp, vp], "oracle_get_counters": [vp, vp],
             "oracle_reset_counters": [vp], "oracle_resize_texture": [vp, u32, u32, vp],
             "oracle_set_node_histogram": [vp, vp], "oracle_trace_vs_brute_force": [vp, vp, u32, vp, vp, vp],
+            "oracle_trace_rays": [vp, vp, u32, ctypes.c_int, vp, vp],
         }.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None
@@ -220,3 +221,17 @@ class OracleRenderer:
         brute = np.empty((n, 4), np.float32)
         self.L.oracle_trace_vs_brute_force(self.ctx, _ptr(rays), n, _ptr(bvh), _ptr(brute), None if skip is None else _ptr(skip))
         return bvh, brute
+
+
+def _trace_rays(self, rays, any_hit=False):
+    """rays (n, 8) f32 {o, t_min, d, t_max} through the restated traversal, ray by ray:
+    -> (out (n, 4) f32 {t, tri, inst, occluded}, counts (n, 2) u64 {nodes_visited, tris_tested})"""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    n = rays.shape[0]
+    out = np.empty((n, 4), np.float32)
+    counts = np.empty((n, 2), np.uint64)
+    self.L.oracle_trace_rays(self.ctx, _ptr(rays), n, 1 if any_hit else 0, _ptr(out), _ptr(counts))
+    return out, counts
+
+
+OracleRenderer.traceRays = _trace_rays

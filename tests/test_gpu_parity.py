@@ -593,3 +593,25 @@ def test_traversal_array_is_the_same_tree_renumbered(W, gpu_renderer, scene):
         ext = tn[:, 4:7] - tn[:, 0:3]
         area = 2 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0])
         assert int((area[:5120] >= area[5120:].max()).sum()) >= 4000
+
+
+@pytest.mark.parametrize("scene", ["cornell", "viewer_diamond", "viewer_diamond_1k", "special", "mixed", "mesh", "instanced1000",
+                                   "sponza_like", "glass_blob"])
+def test_pair_records_equal_the_numpy_restatement(W, gpu_renderer, scene):
+    """The child-pair records the trace kernels walk (csrc/k_pairs.hip.h, built on the GPU at upload) against
+    tests/pair_layout.py, byte for byte — the arrays tests/test_pairwalk_model.py walks on the host against the oracle."""
+    import ctypes
+    import pair_layout
+    b = pu.bridge_for(W, scene)
+    r = gpu_renderer
+    r.buildPipeline(4, 1)
+    W.upload_scene(r, b, 32, 16)
+    pairs, troot, inst_root = pair_layout.build(b.tlas, b.blas, b.instances)
+    got_pairs = np.zeros((len(pairs) + 1, 16), np.float32)
+    got_roots = np.zeros((len(inst_root) + 1, 8), np.float32)
+    vp = ctypes.c_void_p
+    n = r.L.rt_debug_read_pairs(r.ctx, got_pairs.ctypes.data_as(vp), got_roots.ctypes.data_as(vp), len(got_pairs))
+    assert n == len(pairs)
+    assert np.array_equal(got_pairs[:n].view(np.uint32), pairs.view(np.uint32))
+    assert np.array_equal(got_roots[:-1].view(np.uint32), inst_root.view(np.uint32))
+    assert np.array_equal(got_roots[-1].view(np.uint32), troot.view(np.uint32))

@@ -9,6 +9,9 @@
 //   tnodes     2 x float4 / node   the same boxes and leaf words with BOTH successors explicit ({.., skip'} {.., inner |
 //              first child'}), ordered most-visited first so that a prefix can live in LDS (k_treelet.hip.h)
 //   inst_root  u32 / inst          index in tnodes of the instance's BLAS root
+//   pairs      4 x float4 / INNER node   {L.min, wordL} {L.max, 0} {R.min, wordR} {R.max, skipX}: what the wave-level walk of
+//              the trace kernels reads (k_pairs.hip.h, k_pairwalk.hip.h) — both children in one 64-byte-aligned record
+//   root_rec   2 x float4 / inst (+1)    box and word of the instance's BLAS root; the last record is the TLAS root
 //   tri_geom   3 x float4 / tri    {v0, _} {e1 = v1-v0, _} {e2 = v2-v0, _}   (48 B instead of the
 //              80-B topology row + 3 dependent 16-B position gathers, Raytracer.wgsl:476-477)
 //   tri_shade  8 x float4 / tri    rows 1..4 of the topology record (material attributes), then the three vertex normals and
@@ -39,6 +42,8 @@ struct DevScene {
   const float4* nodes;      // 2 per node, TLAS ++ BLAS (bridge layout; the per-lane walks of the primary pass read it)
   const float4* tnodes;     // 2 per node: the same nodes with explicit successors, treelet first (k_treelet.hip.h)
   const uint32_t* inst_root;  // 1 per instance: index in tnodes of the instance's BLAS root
+  const float4* pairs;      // 4 per INNER node: both children's boxes and words + the stackless skip (k_pairs.hip.h)
+  const float4* root_rec;   // 2 per instance: its BLAS root's box and word; record n_instances = the TLAS root
   const float4* tri_geom;   // RT_TRI_STRIDE per triangle: {v0} {e1} {e2} (+ padding to one 64-byte line)
   const float4* tri_shade;  // 8 per triangle: what shading reads about a hit, in ONE 128-byte line
   const float4* inst_trav;  // 4 per instance

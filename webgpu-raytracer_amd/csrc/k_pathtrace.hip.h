@@ -389,12 +389,6 @@ struct LdsPlan {
   uint32_t k_nodes, stage_inst, stage_tri, pad;
 };
 
-// stage `slots` 16-byte records from global memory into LDS at `dst` (all threads of the workgroup; no barrier)
-__device__ __forceinline__ void lds_stage(f4* dst, const void* src, size_t slots) {
-  const f4* g = reinterpret_cast<const f4*>(src);
-  for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) dst[i] = g[i];
-}
-
 // Fill TravMem for the mixed mode and stage what the plan names; returns the number of 16-byte slots used.
 __device__ __forceinline__ uint32_t trav_stage_mixed(TravMem& M, f4* lds, uint32_t slot0, const DevScene& Sg, const LdsPlan& P,
                                                      uint32_t n_tris_total, uint32_t n_inst_total) {

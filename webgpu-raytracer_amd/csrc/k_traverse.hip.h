@@ -26,6 +26,12 @@ __device__ __forceinline__ float rt_opaque(float v) {
   return v;
 }
 
+// stage `slots` 16-byte records from global memory into LDS at `dst` (all threads of the workgroup; no barrier)
+__device__ __forceinline__ void lds_stage(f4* dst, const void* src, size_t slots) {
+  const f4* g = reinterpret_cast<const f4*>(src);
+  for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) dst[i] = g[i];
+}
+
 // Where the traversal records live.  `tnodes` (k_treelet.hip.h) has its first k_lds nodes staged in LDS at slot l_nodes
 // of the workgroup's dynamic LDS array (by default all of them or none, rt_api.hip plan_lds); the triangle records, the
 // instance rows and the instance BLAS roots are staged as a whole when they fit (l_* != RT_LDS_NONE), else read through

@@ -230,10 +230,11 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 // the records among more waves at the price of fewer waves per SIMD (LdsPlan, rt_api.hip plan_lds; measured without gain,
 // DESIGN.md 4.1b).  LDS = true: every traversal record fits (RT_TRAV_LDS).
 #ifndef RT_WF_WAVES
-#define RT_WF_WAVES 6
+#define RT_WF_WAVES 4   // waves per SIMD of the trace kernels: what the per-wave LDS block (work queue + stack, 8.3 KB at K = 8) leaves room for
 #endif
 #ifndef RT_WF_STEPS_PER_TRIP
-#define RT_WF_STEPS_PER_TRIP 6   // node steps between two looks at the ray queue and the triangle queue.  First sweep on
+#define RT_WF_STEPS_PER_TRIP 3   // RECORD fetches (two node tests each) between two looks at the ray queue and the triangle queue.
+                                 // Round 2, single-node steps: first sweep on
                                  // sponza-like (ms per 32 frames): 1: 153.0, 2: 137.7, 3: 134.5, 4: 133.2, 6: 132.0, 8: 131.4.
                                  // Final kernels, (steps, refill) -> ms per frame sponza-like / instanced x1000 / glass blob 4K:
                                  // (4, 16) 4.39 / 2.93 / 10.32, (6, 16) 4.39 / 2.90 / 10.19, (6, 24) 4.31 / 2.95 / 10.11,
@@ -245,25 +246,24 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 __device__ unsigned long long g_trace_sections[2][8];
 template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
-void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
-                uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
+void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_pairs_total,
+                uint32_t n_tris_total, uint32_t n_inst_total, PairPlan plan) {
   extern __shared__ f4 s_scene[];
   WaveWork W;
-  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_PW_BYTES_PER_WAVE;
   wave_work_at(W, wbase);
-  const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
-  TravMem M;
+  LdsStack stk = pw_stack_at(wbase);
+  const uint32_t rec0 = ((BLOCK / 64) * RT_PW_BYTES_PER_WAVE) / 16;
+  PairMem M;
   if (LDS) {
-    LdsPlan all;
-    all.k_nodes = n_nodes_total;
-    all.stage_inst = all.stage_tri = 1u;
+    PairPlan all;
+    all.stage_pairs = all.stage_inst = all.stage_tri = 1u;
     all.pad = 0u;
-    trav_stage_mixed(M, s_scene, rec0, Sg, all, n_tris_total, n_inst_total);
+    pw_stage(M, s_scene, rec0, Sg, all, n_pairs_total, n_tris_total, n_inst_total, RT_T_MIN);
   } else {
-    trav_stage_mixed(M, s_scene, rec0, Sg, plan, n_tris_total, n_inst_total);
+    pw_stage(M, s_scene, rec0, Sg, plan, n_pairs_total, n_tris_total, n_inst_total, RT_T_MIN);
   }
   __syncthreads();
-  constexpr int MODE = LDS ? RT_TRAV_LDS : RT_TRAV_MIXED;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t blas_base = U.blas_base_idx;
   uint32_t* cnt = Q.counters + 8u * depth;
@@ -275,11 +275,11 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   // per-lane ray + traversal state
   bool have_ray = false;
   uint32_t slot = 0u;
-  Trav s;
-  trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), 0.0f);
+  PairLane s;
+  uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
+  pw_start<false>(M, s, false, ANY, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), 0.0f, n_nodes);
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
-  uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
 
 #ifdef RT_TRACE_STAMPS
   unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
@@ -290,10 +290,10 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     st_trips++;
 #endif
     // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
-    const bool done = have_ray && !s.searching && !s.waiting;
+    const bool done = have_ray && s.state == PW_DONE;
     const bool idle = !have_ray || done;
     const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
-    const unsigned long long busy_m = __ballot(s.searching || s.waiting);
+    const unsigned long long busy_m = __ballot(s.state != PW_DONE);
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
          (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
@@ -302,7 +302,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
 #endif
       if (done) {
         if (ANY)
-          Q.occluded[slot] = s.any ? 1u : 0u;
+          Q.occluded[slot] = s.found_any ? 1u : 0u;
         else
           Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
         have_ray = false;
@@ -332,7 +332,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
             slot = qi;
             n_traced++;
             have_ray = true;
-            trav_begin(s, true, blas_base, xyz(r0), xyz(r1), ANY ? r0.w : RT_T_MAX);
+            pw_start<DETAIL>(M, s, true, ANY, blas_base, xyz(r0), xyz(r1), ANY ? r0.w : RT_T_MAX, n_nodes);
           }
         }
       }
@@ -343,20 +343,20 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     st_cyc[0] += st1 - st0;
-    if (__ballot(s.searching) != 0ull) st_cnt[1]++;
+    if (__ballot(pw_can_step(s)) != 0ull) st_cnt[1]++;
 #endif
-    trav_trip<DETAIL, MODE, RT_WF_STEPS_PER_TRIP>(M, s_scene, s, n_nodes);
+    pw_trip<DETAIL, LDS, RT_WF_STEPS_PER_TRIP>(M, s_scene, stk, s, n_nodes);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
     st_cyc[1] += st2 - st1;
-    const bool was_waiting = __ballot(s.waiting) != 0ull;
+    const bool was_waiting = __ballot(s.state == PW_WAIT) != 0ull;
 #endif
-    trav_flush<ANY, DETAIL, MODE>(M, s_scene, W, s, n_tris);
+    pw_flush<DETAIL, LDS>(M, s_scene, W, s, n_tris);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     st_cyc[2] += __builtin_amdgcn_s_memtime() - st2;
-    if (was_waiting && __ballot(s.waiting) == 0ull) st_cnt[2]++;
+    if (was_waiting && __ballot(s.state == PW_WAIT) == 0ull) st_cnt[2]++;
 #endif
   }
 #ifdef RT_TRACE_STAMPS

@@ -7,7 +7,10 @@
 //                             k_primary_visibility: the hardware-raster G-buffer pass (Rasterizer.wgsl:81-173,
 //                             RasterizerPass.ts:97-140) as one closest-hit cast per pixel
 //   k_treelet.hip.h           upload-time re-layout of the node array: explicit successors, most-visited nodes first
-//   k_traverse.hip.h          the wave-level TLAS / BLAS walk (node step + LDS triangle queue), one copy for both forms
+//   k_pairs.hip.h             upload-time re-layout into CHILD-PAIR records (one 64-byte record per inner node)
+//   k_traverse.hip.h          the wave-level TLAS / BLAS walk (node step + LDS triangle queue) of the persistent kernel
+//   k_pairwalk.hip.h          per-ray state machine of the walk over pair records (plain C++: also run on the host by the tests)
+//   k_pairtrav.hip.h          its wave-level side: quad-cooperative record fetch, LDS stack, batched entry, triangle flush
 //   k_pathtrace.hip.h         Raytracer.wgsl `main` + ray_color (:607-819): k_pathtrace, k_pathtrace_persistent
 //   k_wavefront.hip.h         the same bounce as shade / trace stages over device queues (large scenes)
 //   k_texture_post.hip.h      k_resize_texture; k_postprocess = PostProcess.wgsl `main` (:103-176)
@@ -30,7 +33,10 @@
 #include "k_shading.hip.h"
 #include "k_prepare_primary.hip.h"
 #include "k_treelet.hip.h"
+#include "k_pairwalk.hip.h"
+#include "k_pairs.hip.h"
 #include "k_traverse.hip.h"
+#include "k_pairtrav.hip.h"
 #include "k_pathtrace.hip.h"
 #include "k_wavefront.hip.h"
 #include "k_texture_post.hip.h"

@@ -65,8 +65,12 @@ struct rt_ctx {
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, tri_shade, inst_trav, light_rec;
   DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w, treelet_work;   // k_treelet.hip.h
+  DeviceBuffer pairs, pair_of, pair_parent, root_rec;                             // k_pairs.hip.h
+  uint32_t n_pairs = 0;             // inner nodes of the uploaded TLAS ++ BLAS arrays (counted on the host at upload)
+  bool roots_dirty = true;          // root records: rebuilt on every instance upload (cheap); the pair records only when the
+                                    // node array or the SET of BLAS roots changed
   std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
-  bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true;
+  bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true, pairs_dirty = true;
   int wf_block = 0;              // threads per workgroup of the wavefront trace kernels (0 = default; MI355RT_WF_BLOCK)
   size_t lds_per_cu = 160 * 1024;
   bool validate_dirty = true, scene_valid = false;  // k_validate_scene: run once per upload
@@ -339,6 +343,42 @@ int prepare_scene(rt_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     c->nodes_dirty = false;
   }
+  if ((c->pairs_dirty || c->roots_dirty) && c->n_nodes && c->n_instances) {
+    // child-pair records of the walk (k_pairs.hip.h); validate_scene has uploaded the sorted BLAS roots into val_roots and
+    // vouches for every pointer followed here.  An instance upload that keeps the set of BLAS roots only redoes the root
+    // records (one small launch) — what an animated scene pays per update(t).
+    int r;
+    if ((r = ensure_buffer(c, c->pairs, std::max<size_t>(64, (size_t)c->n_pairs * 64), true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->pair_of, (size_t)c->n_nodes * 4, true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->pair_parent, (size_t)c->n_nodes * 4, true)) < 0) return r;
+    if ((r = ensure_buffer(c, c->root_rec, ((size_t)c->n_instances + 1) * 32, true)) < 0) return r;
+    rtk::PairArgs P;
+    P.nodes = (const float4*)c->nodes.ptr;
+    P.pairs = (float4*)c->pairs.ptr;
+    P.pair_of = (uint32_t*)c->pair_of.ptr;
+    P.parent = (uint32_t*)c->pair_parent.ptr;
+    P.roots = (const uint32_t*)c->val_roots.ptr;
+    P.n_nodes = c->n_nodes;
+    P.n_tlas = c->blas_offset;
+    P.n_roots = (uint32_t)c->blas_roots.size();
+    P.pad = 0;
+    if (c->pairs_dirty) {
+      const uint32_t n_blocks = (c->n_nodes + 1023u) / 1024u;
+      if ((r = ensure_buffer(c, c->treelet_work, ((size_t)RT_TREELET_WORK_HEAD + n_blocks) * 4, true)) < 0) return r;
+      uint32_t* work = (uint32_t*)c->treelet_work.ptr;
+      const dim3 grid((c->n_nodes + 255) / 256);
+      hipLaunchKernelGGL(rtk::k_pair_count, dim3(n_blocks), dim3(1024), 0, c->stream, P, work);
+      hipLaunchKernelGGL(rtk::k_treelet_blockscan, dim3(1), dim3(1024), 0, c->stream, work, n_blocks);
+      hipLaunchKernelGGL(rtk::k_pair_number, dim3(n_blocks), dim3(1024), 0, c->stream, P, (const uint32_t*)work);
+      hipLaunchKernelGGL(rtk::k_pair_parent, grid, dim3(256), 0, c->stream, P);
+      hipLaunchKernelGGL(rtk::k_pair_emit, grid, dim3(256), 0, c->stream, P);
+      c->pairs_dirty = false;
+    }
+    hipLaunchKernelGGL(rtk::k_pair_roots, dim3((c->n_instances + 256) / 256), dim3(256), 0, c->stream, P,
+                       (const float4*)c->instances.ptr, (float4*)c->root_rec.ptr, c->n_instances);
+    HIP_TRY(c, hipGetLastError());
+    c->roots_dirty = false;
+  }
   if (c->lights_dirty && c->n_lights && c->n_tris && c->n_instances && c->n_verts) {
     int r = ensure_buffer(c, c->light_rec, (size_t)c->n_lights * 64, true);
     if (r < 0) return r;
@@ -363,6 +403,8 @@ DevScene dev_scene(const rt_ctx* c) {
   s.nodes = (const float4*)c->nodes.ptr;
   s.tnodes = (const float4*)c->tnodes.ptr;
   s.inst_root = (const uint32_t*)c->inst_root.ptr;
+  s.pairs = (const float4*)c->pairs.ptr;
+  s.root_rec = (const float4*)c->root_rec.ptr;
   s.tri_geom = (const float4*)c->tri_geom.ptr;
   s.tri_shade = (const float4*)c->tri_shade.ptr;
   s.inst_trav = (const float4*)c->inst_trav.ptr;
@@ -491,7 +533,7 @@ void rt_destroy(rt_ctx* c) {
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
                          &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
                          &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
-                         &c->inst_root, &c->root_w, &c->treelet_work};
+                         &c->inst_root, &c->root_w, &c->treelet_work, &c->pairs, &c->pair_of, &c->pair_parent, &c->root_rec};
   for (DeviceBuffer* b : all) free_buffer(*b);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
@@ -806,6 +848,7 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
       c->n_instances = (uint32_t)(bytes / sizeof(rt_instance));
       {  // BLAS roots the instances refer to (host copy of one word per instance: the validation kernel needs them sorted)
         const rt_instance* hi = (const rt_instance*)data;
+        const std::vector<uint32_t> old_roots = c->blas_roots;
         c->blas_roots.resize(c->n_instances);
         for (uint32_t k = 0; k < c->n_instances; k++) c->blas_roots[k] = hi[k].blas_node_offset;
         std::sort(c->blas_roots.begin(), c->blas_roots.end());
@@ -823,7 +866,9 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
           const size_t r = std::lower_bound(c->blas_roots.begin(), c->blas_roots.end(), hi[k].blas_node_offset) - c->blas_roots.begin();
           c->root_w_host[r] += (float)s2;
         }
+        if (old_roots != c->blas_roots) c->pairs_dirty = true;   // BLAS-local skips are resolved against the set of roots
       }
+      c->roots_dirty = true;
       c->nodes_dirty = true;
       c->validate_dirty = true;
       c->inst_dirty = true;
@@ -892,8 +937,18 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->blas_offset = n_tlas;  // this.blasOffset = tlas.length / 8
   c->n_nodes = n_tlas + n_blas;
+  {  // inner nodes (data word 0): one child-pair record each
+    uint32_t inner = 0;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tlas);
+    const uint32_t* bw = reinterpret_cast<const uint32_t*>(blas);
+    for (uint32_t k = 0; k < n_tlas; k++) inner += tw[8 * (size_t)k + 7] == 0u;
+    for (uint32_t k = 0; k < n_blas; k++) inner += bw[8 * (size_t)k + 7] == 0u;
+    c->n_pairs = inner;
+  }
+  c->roots_dirty = true;
   c->validate_dirty = true;
   c->nodes_dirty = true;
+  c->pairs_dirty = true;
   return r ? RT_REALLOCATED : RT_OK;
 }
 
@@ -940,6 +995,35 @@ static rtk::LdsPlan plan_lds(const rt_ctx* c, size_t budget, size_t queue_bytes,
     avail -= inst_bytes;
   }
   *dyn_bytes = queue_bytes + (size_t)P.k_nodes * 32 + (P.stage_tri ? tri_bytes : 0) + (P.stage_inst ? inst_bytes : 0);
+  return P;
+}
+
+// The same for the child-pair walk of the trace kernels: pair records, triangle records, instance rows + root records.
+static rtk::PairPlan plan_pairs(const rt_ctx* c, size_t budget, size_t queue_bytes, size_t* dyn_bytes) {
+  rtk::PairPlan P;
+  P.stage_pairs = P.stage_inst = P.stage_tri = P.pad = 0;
+  if (c->no_lds_staging) {
+    *dyn_bytes = queue_bytes;
+    return P;
+  }
+  budget &= ~(size_t)2047;
+  size_t avail = budget > queue_bytes ? budget - queue_bytes : 0;
+  avail &= ~(size_t)15;
+  const size_t pair_bytes = (size_t)c->n_pairs * 64, tri_bytes = (size_t)c->n_tris * 16 * RT_TRI_STRIDE,
+               inst_bytes = (size_t)c->n_instances * 96;
+  if (pair_bytes <= avail) {
+    P.stage_pairs = 1;
+    avail -= pair_bytes;
+  }
+  if (tri_bytes <= avail) {
+    P.stage_tri = 1;
+    avail -= tri_bytes;
+  }
+  if (inst_bytes <= avail) {
+    P.stage_inst = 1;
+    avail -= inst_bytes;
+  }
+  *dyn_bytes = queue_bytes + (P.stage_pairs ? pair_bytes : 0) + (P.stage_tri ? tri_bytes : 0) + (P.stage_inst ? inst_bytes : 0);
   return P;
 }
 
@@ -990,23 +1074,24 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   Q.occluded = (uint32_t*)(qb + qcap * 128);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
   const bool detail = c->detailed_counters;
-  // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
-  // records in LDS.  Otherwise six 256-thread workgroups per CU (6 waves per SIMD), each staging what fits whole in its
-  // sixth of the LDS (plan_lds); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
-  const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
-  const bool trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+  // Workgroup shape of the trace kernels.  Every wave owns RT_PW_BYTES_PER_WAVE of LDS (triangle work queue + the stack of
+  // deferred right children).  Everything fits beside four wave blocks in 64 KB: 256-thread workgroups, all records in
+  // LDS.  Otherwise 256-thread workgroups, as many per CU as the wave blocks allow (4 at K = 8), each staging what fits
+  // whole in its share of the LDS (plan_pairs); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
+  const size_t lds_records = ((size_t)4 * c->n_pairs + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)6 * c->n_instances) * 16;
+  const bool trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_PW_BYTES_PER_WAVE <= 64 * 1024;
   int block = 256, blocks_per_cu = 0;
   if (!trace_lds) {
     block = c->wf_block ? c->wf_block : 256;
-    blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : (block == 1024 ? 1 : (block == 512 ? 2 : 6));
+    const int fit = (int)(c->lds_per_cu / ((size_t)(block / 64) * RT_PW_BYTES_PER_WAVE));
+    blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : std::max(1, std::min(fit, (RT_WF_WAVES * 256) / block));
   }
-  const size_t queue_bytes = (size_t)(block / 64) * RT_WORK_BYTES_PER_WAVE;
+  const size_t queue_bytes = (size_t)(block / 64) * RT_PW_BYTES_PER_WAVE;
   size_t dyn = queue_bytes + lds_records;
-  rtk::LdsPlan plan;
-  plan.k_nodes = c->n_nodes;
-  plan.stage_inst = plan.stage_tri = 1;
+  rtk::PairPlan plan;
+  plan.stage_pairs = plan.stage_inst = plan.stage_tri = 1;
   plan.pad = 0;
-  if (!trace_lds) plan = plan_lds(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+  if (!trace_lds) plan = plan_pairs(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
   const void* trace_fn[2];
   for (int k = 0; k < 2; k++)
     trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds)
@@ -1022,7 +1107,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     c->wf_occ_detail = (int)detail;
     c->wf_occ_block = block;
   }
-  uint32_t nn = c->n_nodes, nt = c->n_tris, ni = c->n_instances;
+  uint32_t nn = c->n_pairs, nt = c->n_tris, ni = c->n_instances;
   EventPair* ev = next_events(c, RT_TIMER_PATHTRACE);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   for (uint32_t depth = 0; depth < depths; depth++) {
@@ -1445,6 +1530,17 @@ int rt_debug_read_traversal_nodes(rt_ctx* c, float* tnodes_out, uint32_t* new_in
   if (inst_root_out) HIP_TRY(c, hipMemcpyAsync(inst_root_out, c->inst_root.ptr, (size_t)c->n_instances * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return (int)c->n_nodes;
+}
+int rt_debug_read_pairs(rt_ctx* c, float* pairs_out, float* root_rec_out, uint32_t cap_pairs) {
+  if (!c) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = prepare_scene(c);
+  if (r < 0) return r;
+  if (cap_pairs < c->n_pairs || !c->pairs.ptr || !c->root_rec.ptr) return fail(c, RT_ERR_INVALID, "rt_debug_read_pairs: no records or buffer too small");
+  if (pairs_out && c->n_pairs) HIP_TRY(c, hipMemcpyAsync(pairs_out, c->pairs.ptr, (size_t)c->n_pairs * 64, hipMemcpyDeviceToHost, c->stream));
+  if (root_rec_out) HIP_TRY(c, hipMemcpyAsync(root_rec_out, c->root_rec.ptr, ((size_t)c->n_instances + 1) * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return (int)c->n_pairs;
 }
 int rt_debug_trace_sections(rt_ctx* c, uint64_t* out16, int reset) {
   if (!c || !out16) return RT_ERR_INVALID;
