@@ -347,7 +347,7 @@ def main():
             roof["pmc_csrc_sha16"] = {"collected_from": ref.get("csrc_sha16"), "this_build": pkg._build.kernel_source_hash()}
         if stale:
             roof["pmc_stale_note"] = ("profiles/pmc_reference.json was collected from other kernel sources than this build's: "
-                                      "achieved / frac / traffic (counter-derived) are withheld; re-run tools/make_profiles.sh")
+                                      "achieved / frac / traffic (counter-derived) are withheld; re-run tools/make_profiles_round.sh")
         if pt.get("lane_instr_per_launch") and launch_ms > 0 and not stale:
             scale = min(args.batch, len(frames)) / float(pt.get("frames_per_launch", 32))
             lane = pt["lane_instr_per_launch"] * scale

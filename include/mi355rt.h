@@ -174,6 +174,12 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Average duration in ms of the path-trace kernel over the launches since the last call
  * (HIP events recorded on the context stream around each launch); also returns the launch count. */
 int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
+/* Traversal of the wavefront trace kernels: 1 = child-pair records (csrc/k_pairwalk.hip.h: one 64-byte record per inner
+ * node, both children tested per fetch, quad-cooperative LDS-DMA fetch, short per-lane stack); 0 = one 32-byte node per step
+ * with skip pointers only (rounds 1-2); 2 (default) = auto: pairs for a scene of one instance, nodes otherwise (where each
+ * was measured faster).  Same results bit for bit, same counters.  MI355RT_WALK=node|pairs|auto sets the
+ * default of new contexts. */
+int rt_set_walk(rt_ctx* ctx, int walk);
 int rt_set_kernel_timing(rt_ctx* ctx, int enabled);
 /* Per-kernel timers (HIP events on the context stream around every launch while timing is enabled): sum of the
  * durations in ms and launch count per RT_TIMER_* since the last read; n = number of entries the arrays hold. */

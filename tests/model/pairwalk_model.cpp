@@ -53,7 +53,7 @@ void trace_one(const float* pairs, const float* troot, const float* inst_trav, c
   bool went_stackless = false;
   while (s.state != PW_DONE) {
     steps++;
-    went_stackless |= s.sl_tlas || s.sl_blas;
+    went_stackless |= (s.flags & (PW_F_SL_TLAS | PW_F_SL_BLAS)) != 0u;
     switch (s.state) {
       case PW_FETCH:
       case PW_FETCHR: {
@@ -67,14 +67,11 @@ void trace_one(const float* pairs, const float* troot, const float* inst_trav, c
       case PW_POP:
         pw_pop<COUNT>(s, stk, n_nodes);
         break;
-      case PW_LEVEL_END:
-        pw_level_end(s);
-        break;
       case PW_ENTER: {
         const float* m = inst_trav + (size_t)s.cur_inst * 16;
         const float* rr = inst_root + (size_t)s.cur_inst * 8;
-        pw_enter<COUNT>(s, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], rr[0], rr[1], rr[2],
-                        fbits(rr[3]), rr[4], rr[5], rr[6], t_min, n_nodes);
+        pw_enter<COUNT, K>(s, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], rr[0], rr[1], rr[2],
+                           fbits(rr[3]), rr[4], rr[5], rr[6], t_min, stk, n_nodes);
         break;
       }
       case PW_WAIT: {
@@ -105,7 +102,7 @@ void trace_one(const float* pairs, const float* troot, const float* inst_trav, c
   out[0] = s.closest;
   out[1] = (float)s.best_tri;
   out[2] = (float)s.best_inst;
-  out[3] = s.found_any ? 1.0f : 0.0f;
+  out[3] = pw_flag(s, PW_F_FOUND) ? 1.0f : 0.0f;
   counts[0] = n_nodes;
   counts[1] = n_tris;
   stats[3] += steps;

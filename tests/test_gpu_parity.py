@@ -354,13 +354,16 @@ def test_batched_dispatch_with_stripes(W, gpu_renderer):
     ("glass_blob", 48, 27, 16, (1, 2), 1),
     ("cornell", 33, 21, 1, (1, 2), 2),                      # MAX_DEPTH = 1: no extension rays at all
 ])
-def test_wavefront_form_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, frames, batch):
+@pytest.mark.parametrize("walk", [1, 0])
+def test_wavefront_form_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, frames, batch, walk):
     """Kernel variant 2 (shade / trace stages with the path state in HBM) against the oracle: accumulation, G-buffer,
-    uniforms and all six counters; then present()."""
+    uniforms and all six counters; then present().  walk 1 = child-pair records (the default), 0 = the single-node walk
+    kept for A/B measurements: both must reach every node the reference reaches, in its order (nodes_visited, tris_tested)."""
     b = pu.bridge_for(W, scene)
     cpu = oracle_lib.OracleRenderer()
     pu.drive(cpu, W, b, w, h, depth, 1, frames, present=False)
     gpu_renderer.setKernelVariant(2)
+    gpu_renderer.setWalk(walk)
     gpu_renderer.buildPipeline(depth, 1)
     W.upload_scene(gpu_renderer, b, w, h)
     gpu_renderer.setCounting(True)

@@ -5,7 +5,7 @@
 // record (1 = 16 B of a 32-B record, 2 = the 32-B node of k_traverse.hip.h, 4 = a 64-byte-aligned 64-B PAIR of nodes:
 // the table is then a permutation of n/2 64-byte records, so a 4-load walk wanders over the whole table like the others
 // — round 2's 4-load rows followed the successor of the even 32-B record only and collapsed into a short cached cycle),
-// `lanes` lanes of every wave active, `blocks` 256-thread workgroups per CU.  "4q" = the same 64-byte records fetched
+// `lanes` lanes of every wave active, `blocks` 256-thread workgroups per CU.  "4q" (registers) and "4d" (LDS-DMA) = the same 64-byte records fetched
 // QUAD-COOPERATIVELY: four lanes read the four 16-byte chunks of ONE ray's record in one instruction (four instructions
 // serve the 64 rays of a wave; each instruction touches 16 lines instead of 64), the successor word handed to the
 // owning lane by a DPP quad broadcast.  Table sizes walk the hierarchy: 16 KB (vector L1), 1 MB (L2), 4 MB
@@ -102,6 +102,43 @@ __global__ __launch_bounds__(256) void k_chase_quad(const f4* tab, uint32_t n_re
   }
 }
 
+// "4d": the quad-cooperative fetch with the data landing in LDS (global_load_lds_dwordx4, per-lane source address): instruction
+// k writes the 64 rays' ... no: the 16 records of the rays 4q + k as one contiguous KB at its own LDS region (M0), quad q's
+// four lanes supplying the four chunks of record q; the owner then reads its record back (here: chunk 0 for the successor,
+// the other three summed so that they are not dead).  No register shuffling at all — what the trace kernels use.
+typedef __attribute__((address_space(1))) const void* gvptr;
+typedef __attribute__((address_space(3))) void* lvptr;
+__global__ __launch_bounds__(256) void k_chase_quad_dma(const f4* tab, uint32_t n_rec, uint32_t lanes, int iters, float* out,
+                                                        unsigned long long* stamps) {
+  extern __shared__ f4 dma_lds[];   // per wave 4 regions of 1 KB + 16 B of padding each (bank spread for the read-back)
+  const uint32_t lane = threadIdx.x & 63u, c = lane & 3u, qbase = lane & ~3u, wave = threadIdx.x >> 6;
+  f4* wl = dma_lds + wave * 4u * 65u;
+  uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u % n_rec;
+  float acc = 0.0f;
+  const f4* mine = wl + c * 65u + (lane >> 2) * 4u;   // the owner's record: region (lane & 3), record (lane >> 2)
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+    const uint32_t i0 = quad_bcast<0>(idx), i1 = quad_bcast<1>(idx), i2 = quad_bcast<2>(idx), i3 = quad_bcast<3>(idx);
+    if (qbase + 0u < lanes) __builtin_amdgcn_global_load_lds((gvptr)(tab + 4 * (size_t)i0 + c), (lvptr)(wl + 0u * 65u), 16, 0, 0);
+    if (qbase + 1u < lanes) __builtin_amdgcn_global_load_lds((gvptr)(tab + 4 * (size_t)i1 + c), (lvptr)(wl + 1u * 65u), 16, 0, 0);
+    if (qbase + 2u < lanes) __builtin_amdgcn_global_load_lds((gvptr)(tab + 4 * (size_t)i2 + c), (lvptr)(wl + 2u * 65u), 16, 0, 0);
+    if (qbase + 3u < lanes) __builtin_amdgcn_global_load_lds((gvptr)(tab + 4 * (size_t)i3 + c), (lvptr)(wl + 3u * 65u), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < lanes) {
+      const f4 a = mine[0], b = mine[1], cc = mine[2], d = mine[3];
+      acc += a.x + b.y + cc.z + d.x;
+      idx = __float_as_uint(a.w);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = acc + (float)idx;
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = c1 - c0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 template <int LOADS>
 __global__ __launch_bounds__(256) void k_chase_lds(const f4* tab, uint32_t n_rec, uint32_t lanes, int iters, float* out) {
   extern __shared__ f4 lds[];
@@ -169,7 +206,7 @@ int main() {
         host[(size_t)per * i].w = fw;
       }
       CHECK(hipMemcpy(tab, host.data(), (size_t)n_rec * 32, hipMemcpyHostToDevice));
-      for (int loads : {1, 2, 4, 5}) {   // 5 = "4q": the 64-byte records fetched quad-cooperatively
+      for (int loads : {1, 2, 4, 5, 6}) {   // 5 = "4q": the 64-byte records fetched quad-cooperatively; 6 = "4d": the same into LDS
         if ((layout == 0) != (loads <= 2)) continue;
         for (uint32_t lanes : {64u, 40u, 16u}) {
           for (int blocks : {2, 4, 6, 8}) {
@@ -183,6 +220,7 @@ int main() {
               if (loads == 2) hipLaunchKernelGGL(k_chase<2>, dim3(grid), dim3(256), 0, 0, tab, n_walk, lanes, iters, out, stamps);
               if (loads == 4) hipLaunchKernelGGL(k_chase<4>, dim3(grid), dim3(256), 0, 0, tab, n_walk, lanes, iters, out, stamps);
               if (loads == 5) hipLaunchKernelGGL(k_chase_quad, dim3(grid), dim3(256), 0, 0, tab, n_walk, lanes, iters, out, stamps);
+              if (loads == 6) hipLaunchKernelGGL(k_chase_quad_dma, dim3(grid), dim3(256), 4 * 4 * 65 * 16, 0, tab, n_walk, lanes, iters, out, stamps);
               CHECK(hipEventRecord(e1));
               CHECK(hipEventSynchronize(e1));
               CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -192,11 +230,11 @@ int main() {
             for (int b = 0; b < grid; b++) clk += (double)hs[2 * b] / (double)hs[2 * b + 1] * 0.1;
             clk /= grid;
             const double steps = (double)grid * 4 * lanes * iters;
-            const int instr = loads == 5 ? 4 : loads;   // wave-level load instructions per step
+            const int instr = loads >= 5 ? 4 : loads;   // wave-level load instructions per step
             const double cyc_step = clk * 1e9 * ms * 1e-3 / ((double)blocks * 4 * iters);
             printf("%-8s %-6s %-6u %-7d %14.1f %16.1f %12.1f %10.2f\n",
                    n_rec == 512u ? "16KB" : n_rec == 32768u ? "1MB" : n_rec == 131072u ? "4MB" : "64MB",
-                   loads == 5 ? "4q" : (loads == 4 ? "4" : (loads == 2 ? "2" : "1")), lanes, blocks,
+                   loads == 6 ? "4d" : (loads == 5 ? "4q" : (loads == 4 ? "4" : (loads == 2 ? "2" : "1"))), lanes, blocks,
                    steps / (ms * 1e-3) * 1e-9, cyc_step / instr, cyc_step, clk);
             fflush(stdout);
           }

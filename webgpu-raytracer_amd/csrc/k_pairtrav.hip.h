@@ -9,7 +9,7 @@
 namespace rtk {
 
 #ifndef RT_PW_STACK_K
-#define RT_PW_STACK_K 8   // deferred right children a lane can hold (8 bytes each in LDS).  Fall-back rate measured on the
+#define RT_PW_STACK_K 7   // deferred right children a lane can hold (8 bytes each in LDS).  Fall-back rate measured on the
                           // host model (tests/test_pairwalk_model.py, random rays): K = 8: 0.3 % of the rays of the 263 k-
                           // triangle scene leave the stack, +0.5 % record fetches; K = 6: 2.7 %, +3 %; K = 4: 14 %, +15 %
 #endif
@@ -24,7 +24,14 @@ typedef unsigned long long __attribute__((address_space(3))) * rt_lptr64;
 // Where the walk's records live.  Pair records: all of them in LDS (l_pairs set: small scenes) or all in global memory;
 // triangle records, instance rows and root records likewise, each on its own.  Slots are 16-byte units of the
 // workgroup's dynamic LDS array.
+struct TlasRoot {       // the TLAS root's box and word, by value in the kernel arguments (rt_api.hip fills it at upload)
+  float lo[3];
+  uint32_t word;
+  float hi[3];
+  uint32_t pad;
+};
 struct PairMem {
+  TlasRoot troot;
   const f4* gpairs;     // 4 per pair record
   const f4* gtri;       // tri_geom, RT_TRI_STRIDE per triangle
   const f4* ginst;      // inst_trav, 4 per instance
@@ -55,6 +62,7 @@ __device__ __forceinline__ LdsStack pw_stack_at(char* wave_base) {   // wave_bas
 // not at all.
 struct PairPlan {
   uint32_t stage_pairs, stage_inst, stage_tri, pad;
+  TlasRoot troot;
 };
 // Fill PairMem and stage what the plan names (all threads of the workgroup; the caller synchronises).
 __device__ __forceinline__ void pw_stage(PairMem& M, f4* lds, uint32_t slot0, const DevScene& Sg, const PairPlan& P, uint32_t n_pairs,
@@ -66,6 +74,7 @@ __device__ __forceinline__ void pw_stage(PairMem& M, f4* lds, uint32_t slot0, co
   M.groot = reinterpret_cast<const f4*>(Sg.root_rec);
   M.n_inst = n_inst;
   M.t_min = t_min;
+  M.troot = P.troot;
   M.l_pairs = M.l_tri = M.l_inst = M.l_root = RT_LDS_NONE;
   if (P.stage_pairs) {
     M.l_pairs = slot;
@@ -87,83 +96,112 @@ __device__ __forceinline__ void pw_stage(PairMem& M, f4* lds, uint32_t slot0, co
   }
 }
 
-// ---- DPP helpers (quad = 4 consecutive lanes).  Called from wave-uniform control flow only: a DPP read of a lane that
-// is switched off returns 0 (bound_ctrl), not that lane's register.
+// ---- DPP helper (quad = 4 consecutive lanes).  Called from wave-uniform control flow only: a DPP read of a lane that is
+// switched off returns 0 (bound_ctrl), not that lane's register.
 template <int QP>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {   // lane QP of the quad, to all four
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, QP * 0x55, 0xf, 0xf, true);
 }
-template <int ROT>
-__device__ __forceinline__ float quad_rot(float v) {           // lane r receives the value of lane (r + ROT) & 3
-  constexpr int ctrl = ((0 + ROT) & 3) | (((1 + ROT) & 3) << 2) | (((2 + ROT) & 3) << 4) | (((3 + ROT) & 3) << 6);
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
-}
-template <int ROT>
-__device__ __forceinline__ f4 quad_rot4(f4 v) {
-  f4 r;
-  r.x = quad_rot<ROT>(v.x); r.y = quad_rot<ROT>(v.y); r.z = quad_rot<ROT>(v.z); r.w = quad_rot<ROT>(v.w);
-  return r;
-}
-__device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) {   // c ? a : b, per component (v_cndmask)
-  f4 r;
-  r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; r.w = c ? a.w : b.w;
-  return r;
-}
 
-// QUAD-COOPERATIVE fetch of 64-byte pair records from global memory.  Instruction k (k = 0..3) serves the rays of the
-// lanes 4q + k: the four lanes of quad q read the four 16-byte chunks of THAT ray's record — one 64-byte line per quad
-// and instruction instead of one line per lane — lane 4q + c taking chunk (c - k) & 3.  Measured (tools/gather_peak.hip
-// rows "4q"): a step costs the texture-address path what ONE 16-byte load per lane cost, L1-resident or not.  Then every
-// lane rotates its four registers by its own position (two rounds of selects) and three quad rotations (DPP) hand each
-// owner the chunks 1..3 of its record; chunk 0 is its own.
-__device__ __forceinline__ void pw_fetch_quad(const f4* gpairs, bool need, uint32_t idx, f4& q0, f4& q1, f4& q2, f4& q3) {
-  const uint32_t c = threadIdx.x & 3u;
+typedef __attribute__((address_space(1))) const void* rt_gvptr;
+typedef __attribute__((address_space(3))) void* rt_lvptr;
+
+// QUAD-COOPERATIVE fetch of 64-byte pair records from global memory, landing in LDS (global_load_lds_dwordx4).
+// Instruction k (k = 0..3) serves the rays of the lanes 4q + k: the four lanes of quad q read the four 16-byte chunks of THAT
+// ray's record — one 64-byte line per quad and instruction instead of one line per lane — and the instruction's 64 x 16
+// bytes land as one contiguous KB in LDS region k, i.e. as 16 whole records; the owner then reads its record back with
+// four ds_read_b128.  Measured (tools/gather_peak.hip, rows "4d"): a step costs the texture-address path what ONE 16-byte
+// load per lane cost (L1-resident 67-72 CU cycles at 40-64 lanes, L2-resident 92-97 / 149), and no register is shuffled
+// (the same fetch through registers, rows "4q", needs 44 selects + DPP moves per step: the first version of this walk was
+// VALU-bound on them).  The four regions (1 KB + 16 B of padding each, so that the read-back spreads over all banks) lie
+// over the wave's triangle work queue, which is only live inside pw_flush.
+#define RT_PW_REGION_SLOTS 65u   // 16-byte slots per region
+__device__ __forceinline__ void pw_fetch_dma(const f4* gpairs, f4* wave_lds, unsigned long long need_mask, uint32_t idx) {
+  const uint32_t c16 = (threadIdx.x & 3u) * 16u;
   const uint32_t i0 = quad_bcast<0>(idx), i1 = quad_bcast<1>(idx), i2 = quad_bcast<2>(idx), i3 = quad_bcast<3>(idx);
-  const uint32_t nd = need ? 1u : 0u;
-  const bool n0 = quad_bcast<0>(nd) != 0u, n1 = quad_bcast<1>(nd) != 0u, n2 = quad_bcast<2>(nd) != 0u, n3 = quad_bcast<3>(nd) != 0u;
-  f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
-  if (n0) v0 = ld_g(gpairs, 4 * (size_t)i0 + c);
-  if (n1) v1 = ld_g(gpairs, 4 * (size_t)i1 + ((c + 3u) & 3u));
-  if (n2) v2 = ld_g(gpairs, 4 * (size_t)i2 + ((c + 2u) & 3u));
-  if (n3) v3 = ld_g(gpairs, 4 * (size_t)i3 + ((c + 1u) & 3u));
-  // u[i] = v[(i + c) & 3]: rotate the register file of the lane left by its position in the quad
-  const bool b0 = (c & 1u) != 0u, b1 = (c & 2u) != 0u;
-  const f4 a0 = sel4(b0, v1, v0), a1 = sel4(b0, v2, v1), a2 = sel4(b0, v3, v2), a3 = sel4(b0, v0, v3);
-  const f4 u0 = sel4(b1, a2, a0), u1 = sel4(b1, a3, a1), u2 = sel4(b1, a0, a2), u3 = sel4(b1, a1, a3);
-  // chunk j of the owner's record sits in lane (owner + j) & 3, in that lane's u[(4 - j) & 3]
-  q0 = u0;
-  q1 = quad_rot4<1>(u3);
-  q2 = quad_rot4<2>(u2);
-  q3 = quad_rot4<3>(u1);
+  // lanes of instruction k: every quad whose lane k wants a record (scalar arithmetic on the ballot: bit 4q + k -> bits 4q..4q+3)
+  const unsigned long long every4 = 0x1111111111111111ull;
+  const unsigned long long m0 = (need_mask & every4) * 15ull, m1 = ((need_mask >> 1) & every4) * 15ull,
+                           m2 = ((need_mask >> 2) & every4) * 15ull, m3 = ((need_mask >> 3) & every4) * 15ull;
+  const char* base = reinterpret_cast<const char*>(gpairs);
+  if (__builtin_amdgcn_inverse_ballot_w64(m0))
+    __builtin_amdgcn_global_load_lds((rt_gvptr)(base + (size_t)(i0 * 64u + c16)), (rt_lvptr)(wave_lds + 0u * RT_PW_REGION_SLOTS), 16, 0, 0);
+  if (__builtin_amdgcn_inverse_ballot_w64(m1))
+    __builtin_amdgcn_global_load_lds((rt_gvptr)(base + (size_t)(i1 * 64u + c16)), (rt_lvptr)(wave_lds + 1u * RT_PW_REGION_SLOTS), 16, 0, 0);
+  if (__builtin_amdgcn_inverse_ballot_w64(m2))
+    __builtin_amdgcn_global_load_lds((rt_gvptr)(base + (size_t)(i2 * 64u + c16)), (rt_lvptr)(wave_lds + 2u * RT_PW_REGION_SLOTS), 16, 0, 0);
+  if (__builtin_amdgcn_inverse_ballot_w64(m3))
+    __builtin_amdgcn_global_load_lds((rt_gvptr)(base + (size_t)(i3 * 64u + c16)), (rt_lvptr)(wave_lds + 3u * RT_PW_REGION_SLOTS), 16, 0, 0);
+}
+__device__ __forceinline__ void pw_fetch_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records are in LDS (an LDS-DMA load counts in vmcnt)
 }
 
 // can this lane still move without the wave's help?
 __device__ __forceinline__ bool pw_can_step(const PairLane& s) {
-  return s.state == PW_FETCH || s.state == PW_FETCHR || s.state == PW_POP || s.state == PW_LEVEL_END;
+  return s.state == PW_FETCH || s.state == PW_FETCHR || s.state == PW_POP;
 }
 __device__ __forceinline__ bool pw_busy(const PairLane& s) { return s.state != PW_DONE; }
 
 #ifndef RT_PW_ENTER_BATCH
 #define RT_PW_ENTER_BATCH 16u   // lanes that wait for an instance entry before the wave does it (deferred entry, as before)
 #endif
+#ifndef RT_PW_POP_REPS
+#define RT_PW_POP_REPS 1        // pops a lane may take between two record fetches (2: a popped child that fails its re-test, or
+                                // the way out of an instance, is followed by the next entry at once — swept 1 / 2 / 3 on MI355X,
+                                // ms per 32-frame batch of the 263 k-triangle hall: 184.7 / 187.0 / 189.6)
+#endif
 
-// STEPS record fetches for every lane that wants one, with the cheap transitions (pop, leave an instance, enter one) in
-// between.  LDS = every record is in LDS (plain ds_read, entry on the spot).
+// STEPS record fetches for every lane that wants one, with the cheap transitions (pop, enter an instance) in between.
+// LDS = every record is in LDS (plain ds_read, entry on the spot).  wave_lds: this wave's LDS block (the fetch regions lie
+// over its triangle work queue).
+// Diagnostic build only (-DRT_PW_STAMPS, tools/exp/pw_sections.py): s_memtime cycles a wave spends in the parts of one round
+// of pw_trip, each closed by s_waitcnt 0: [0] asking for records, [1] pops, [2] instance entry, [3] waiting for + reading the
+// records, [4] slab tests + decision; [5] rounds.  Nothing else reads it; the product build executes no stamp.
+#ifdef RT_PW_STAMPS
+#define PW_STAMP(k)                                                \
+  {                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+    pw_cyc[k] += t_ - pw_t;                                        \
+    pw_t = t_;                                                     \
+  }
+#else
+#define PW_STAMP(k)
+#endif
 template <bool COUNT, bool LDS, int STEPS>
-__device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, LdsStack& stk, PairLane& s, uint32_t& n_nodes) {
+__device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, f4* wave_lds, LdsStack& stk, PairLane& s, uint32_t& n_nodes
+#ifdef RT_PW_STAMPS
+                                        , unsigned long long* pw_cyc
+#endif
+) {
+#ifdef RT_PW_STAMPS
+  unsigned long long pw_t = __builtin_amdgcn_s_memtime();
+#endif
   const bool inst_lds = LDS || M.l_inst != RT_LDS_NONE;   // wave-uniform
+  // this lane's record in the fetch regions: region (lane & 3), record (lane >> 2)
+  const uint32_t lane = threadIdx.x & 63u;
+  const f4* mine = wave_lds + (lane & 3u) * RT_PW_REGION_SLOTS + (lane >> 2) * 4u;
 #pragma unroll
   for (int k = 0; k < STEPS; k++) {
-    // ---- transitions that need no record: twice, so that "level ended -> pop the TLAS entry" costs no extra round
+    // ---- the lanes that know their next record ask for it first (global memory: the LDS-DMA loads are in flight while
+    //      the other lanes pop / enter below; those lanes fetch in the next round)
+    bool need = s.state == PW_FETCH || s.state == PW_FETCHR;
+    unsigned long long need_mask = __ballot(need);
+    if (!LDS && need_mask != 0ull) pw_fetch_dma(M.gpairs, wave_lds, need_mask, s.curr);
+#ifdef RT_PW_STAMPS
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[0] += t_ - pw_t; pw_t = t_; pw_cyc[5]++; }   // no wait here: the loads stay in flight
+#endif
+    // ---- transitions that need no record
 #pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
-      if (__ballot(s.state == PW_LEVEL_END) != 0ull) {
-        if (s.state == PW_LEVEL_END) pw_level_end(s);
-      }
+    for (int rep = 0; rep < RT_PW_POP_REPS; rep++) {
       if (__ballot(s.state == PW_POP) != 0ull) {
         if (s.state == PW_POP) pw_pop<COUNT>(s, stk, n_nodes);
       }
     }
+#ifdef RT_PW_STAMPS
+    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[1] += t_ - pw_t; pw_t = t_; }
+#endif
     // ---- instance entry: on the spot when the rows are in LDS; else when enough lanes wait, or nobody else can move
     {
       const unsigned long long em = __ballot(s.state == PW_ENTER);
@@ -183,14 +221,18 @@ __device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, LdsStac
             b0 = ld_g(M.groot, 2 * (size_t)s.cur_inst + 0);
             b1 = ld_g(M.groot, 2 * (size_t)s.cur_inst + 1);
           }
-          pw_enter<COUNT>(s, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, b0.x, b0.y, b0.z,
-                          rt_f2u(b0.w), b1.x, b1.y, b1.z, M.t_min, n_nodes);
+          pw_enter<COUNT, (uint32_t)RT_PW_STACK_K>(s, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, b0.x,
+                                                   b0.y, b0.z, rt_f2u(b0.w), b1.x, b1.y, b1.z, M.t_min, stk, n_nodes);
         }
       }
     }
-    // ---- one pair record for every lane that wants one
-    const bool need = s.state == PW_FETCH || s.state == PW_FETCHR;
-    if (__ballot(need) != 0ull) {
+    PW_STAMP(2)
+    // ---- the records are there: test both children, decide (records in LDS: the lanes that have just popped come along)
+    if (LDS) {
+      need = s.state == PW_FETCH || s.state == PW_FETCHR;
+      need_mask = __ballot(need);
+    }
+    if (need_mask != 0ull) {
       f4 q0, q1, q2, q3;
       if (LDS) {
         if (need) {
@@ -200,12 +242,20 @@ __device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, LdsStac
           q3 = ld_l(lds, M.l_pairs + 4u * s.curr + 3u);
         }
       } else {
-        pw_fetch_quad(M.gpairs, need, s.curr, q0, q1, q2, q3);
+        pw_fetch_wait();
+        if (need) {
+          q0 = ld_l(mine, 0u);
+          q1 = ld_l(mine, 1u);
+          q2 = ld_l(mine, 2u);
+          q3 = ld_l(mine, 3u);
+        }
       }
+      PW_STAMP(3)
       if (need)
         pw_pair<COUNT, (uint32_t)RT_PW_STACK_K>(s, s.curr, q0.x, q0.y, q0.z, rt_f2u(q0.w), q1.x, q1.y, q1.z, q2.x, q2.y, q2.z,
                                                 rt_f2u(q2.w), q3.x, q3.y, q3.z, rt_f2u(q3.w), M.t_min, stk, n_nodes);
     }
+    PW_STAMP(4)
   }
 }
 
@@ -232,7 +282,7 @@ __device__ __forceinline__ bool pw_flush(const PairMem& M, const f4* lds, const 
   const uint32_t first = s.leaf >> 3;
   if (waiting) {
     f4 ra, rb;
-    ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = rt_u2f(s.any ? 1u : 0u);
+    ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = rt_u2f(s.flags & PW_F_ANY);
     rb.x = rt_opaque(s.r.d.x); rb.y = rt_opaque(s.r.d.y); rb.z = rt_opaque(s.r.d.z); rb.w = s.closest;
     W.rays[2 * lane] = ra;
     W.rays[2 * lane + 1] = rb;
@@ -284,28 +334,32 @@ __device__ __forceinline__ bool pw_flush(const PairMem& M, const f4* lds, const 
   if (waiting) {
     const unsigned long long best = W.res[lane];
     const bool found = best != ~0ull;
-    if (COUNT) n_tris += (s.any && found) ? ((uint32_t)best - first + 1u) : cnt;   // the any-hit loop stops at its first hit
+    if (COUNT) n_tris += (pw_flag(s, PW_F_ANY) && found) ? ((uint32_t)best - first + 1u) : cnt;   // the any-hit loop stops at its first hit
     pw_after_leaf(s, found, rt_u2f((uint32_t)(best >> 32)), (uint32_t)best);
   }
   __builtin_amdgcn_wave_barrier();
   return true;
 }
 
-// start a ray: the TLAS root comes from its own record (wave-uniform address: scalar loads)
+// start a ray: the TLAS root comes from the kernel arguments (scalar registers)
 template <bool COUNT>
 __device__ __forceinline__ void pw_start(const PairMem& M, PairLane& s, bool active, bool any, uint32_t blas_base, rt3 o, rt3 d,
                                          float t_max, uint32_t& n_nodes) {
-  const f4 t0 = ld_g(M.groot, 2 * (size_t)M.n_inst), t1 = ld_g(M.groot, 2 * (size_t)M.n_inst + 1);
-  pw_begin<COUNT>(s, active && blas_base != 0u, any, o, d, M.t_min, t_max, t0.x, t0.y, t0.z, rt_f2u(t0.w), t1.x, t1.y, t1.z,
-                  n_nodes);
+  pw_begin<COUNT>(s, active && blas_base != 0u, any, o, d, M.t_min, t_max, M.troot.lo[0], M.troot.lo[1], M.troot.lo[2],
+                  M.troot.word, M.troot.hi[0], M.troot.hi[1], M.troot.hi[2], n_nodes);
 }
 
 // the whole walk of one wave's rays (persistent kernel): every lane brings one ray
 template <bool COUNT, bool LDS>
-__device__ __forceinline__ void pw_traverse(const PairMem& M, const f4* lds, const WaveWork& W, LdsStack& stk, PairLane& s,
-                                            uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ void pw_traverse(const PairMem& M, const f4* lds, f4* wave_lds, const WaveWork& W, LdsStack& stk,
+                                            PairLane& s, uint32_t& n_nodes, uint32_t& n_tris) {
   for (;;) {
-    pw_trip<COUNT, LDS, RT_PW_STEPS_PER_TRIP>(M, lds, stk, s, n_nodes);
+#ifdef RT_PW_STAMPS
+    unsigned long long unused_cyc[6] = {0, 0, 0, 0, 0, 0};
+    pw_trip<COUNT, LDS, RT_PW_STEPS_PER_TRIP>(M, lds, wave_lds, stk, s, n_nodes, unused_cyc);
+#else
+    pw_trip<COUNT, LDS, RT_PW_STEPS_PER_TRIP>(M, lds, wave_lds, stk, s, n_nodes);
+#endif
     if (!pw_flush<COUNT, LDS>(M, lds, W, s, n_tris)) break;
   }
 }

@@ -24,6 +24,7 @@
 //   * Counters: a node counts when it is reached (L at the fetch; R when L missed, when it is popped, or on a stackless
 //     arrival) — in the counting (DETAIL) build R is pushed even when it already failed (A = NaN: the pop counts it and
 //     moves on), so nodes_visited equals the oracle's, also for shadow rays that end early.
+//   * Entering an instance pushes a sentinel; popping it is how a lane leaves the instance again (world-space ray back).
 //   * Stack overflow (K entries per lane): the level (TLAS or BLAS) drops its entries and goes on STACKLESS, with the
 //     skip pointers every record still carries (q3.w: where the walk goes after this subtree); dropped entries are
 //     later in pre-order than the walk, so it simply reaches them again.  A stackless arrival re-reads a pair record
@@ -36,14 +37,16 @@ namespace rtk {
 #define RT_PAIR_INNER 0x80000000u   // child word: inner node -> low bits = index of the child's own pair record
 #define RT_REF_END 0xffffffffu      // skip reference: the walk leaves the TLAS / the BLAS
 
+#define RT_PW_SENTINEL 0x7ffffff0u  // stack word pushed at instance entry: popping it leaves the instance (no leaf word
+                                    // looks like it: triangle ids stay below 2^26, k_traverse.hip.h items)
+
 // lane states
 #define PW_DONE 0u        // no ray, or the ray's walk is over
 #define PW_FETCH 1u       // fetch pair record `curr`, test both children
 #define PW_FETCHR 2u      // stackless arrival at the RIGHT child of pair `curr`: fetch the record, test R only
-#define PW_POP 3u         // take the next pending right child from the stack
+#define PW_POP 3u         // take the next pending entry from the stack (a right child, or the way out of the instance)
 #define PW_WAIT 4u        // BLAS leaf queued, waiting for the wave's triangle flush
 #define PW_ENTER 5u       // TLAS leaf hit: instance entry pending (batched)
-#define PW_LEVEL_END 6u   // nothing left on this level: leave the instance / finish
 
 #ifndef RT_HD
 #define RT_HD __host__ __device__ __forceinline__
@@ -61,6 +64,14 @@ RT_HD PwRay pw_make_ray(rt3 o, rt3 d) {  // make_ray, Raytracer.wgsl:83-86
   return r;
 }
 
+// lane flags (one register: as separate bools the compiler kept them as scalar lane masks and spent three or four scalar
+// instructions on every conditional update)
+#define PW_F_IN_BLAS 1u
+#define PW_F_ANY 2u        // shadow ray: the first accepted hit ends the walk
+#define PW_F_FOUND 4u      // ... and it was found
+#define PW_F_SL_TLAS 8u    // the TLAS level has dropped its stack entries and walks stackless
+#define PW_F_SL_BLAS 16u   // the same for the BLAS the lane is in
+
 struct PairLane {
   PwRay r;                  // the ray in the space it is walking (world or instance)
   PwRay rw;                 // the world-space ray
@@ -68,12 +79,14 @@ struct PairLane {
   int32_t best_tri, best_inst;
   uint32_t curr;            // pair record to fetch (PW_FETCH / PW_FETCHR)
   uint32_t cur_inst, leaf;
-  uint32_t sp, floor;       // stack entries in use; while in a BLAS, entries [0, floor) belong to the TLAS level
+  uint32_t sp, floor;       // stack entries in use; while in a BLAS, entries [0, floor) belong to the TLAS level (the last of
+                            // them is the sentinel of the instance)
   uint32_t resume;          // stackless level: where the walk goes after the leaf / instance it is busy with
   uint32_t tlas_resume;     // stackless TLAS: where the TLAS walk goes after the instance it is in
   uint32_t state;
-  bool in_blas, any, found_any, sl_tlas, sl_blas;
+  uint32_t flags;
 };
+RT_HD bool pw_flag(const PairLane& s, uint32_t f) { return (s.flags & f) != 0u; }
 
 // slab test of one child (intersect_aabb, Raytracer.wgsl:433-441): hit iff max(t_min, near) <= min(t_max, far);
 // a_out = max(t_min, near), never NaN (t_min is not) — what a deferred right child is re-tested with
@@ -90,25 +103,28 @@ RT_HD bool pw_box(float lx, float ly, float lz, float hx, float hy, float hz, co
   return tm_near <= tm_far;
 }
 
-// the walk is at a node whose test has just passed: descend, queue the leaf, or ask for the instance
-// `after`: stackless successor of this node's subtree (only read on a stackless level)
-RT_HD void pw_child(PairLane& s, uint32_t word, uint32_t after) {
-  // written as selects on the values: as branches that store into one field or another the compiler formed a pointer
-  // select and the lane state went to scratch memory
+// The walk is at a node whose test has just passed (`take`; nothing happens otherwise): descend, queue the leaf, or ask for
+// the instance.  `after`: stackless successor of this node's subtree (only read on a stackless level).  Everything is a
+// select on the values: straight-line code, no lane-mask juggling (and as branches that store into one field or another
+// the compiler formed a pointer select and the lane state went to scratch memory).
+RT_HD void pw_child(PairLane& s, uint32_t word, uint32_t after, bool take) {
   const bool inner = (word & RT_PAIR_INNER) != 0u;
-  const bool blas_leaf = !inner && s.in_blas, tlas_leaf = !inner && !s.in_blas;
-  s.curr = inner ? (word & ~RT_PAIR_INNER) : s.curr;
+  const bool in_blas = pw_flag(s, PW_F_IN_BLAS);
+  const bool blas_leaf = take && !inner && in_blas, tlas_leaf = take && !inner && !in_blas;
+  s.curr = (take && inner) ? (word & ~RT_PAIR_INNER) : s.curr;
   s.leaf = blas_leaf ? word : s.leaf;
   s.resume = blas_leaf ? after : s.resume;
   s.cur_inst = tlas_leaf ? (word >> 3) : s.cur_inst;
   s.tlas_resume = tlas_leaf ? after : s.tlas_resume;
-  s.state = inner ? PW_FETCH : (blas_leaf ? PW_WAIT : PW_ENTER);
+  const uint32_t st = inner ? PW_FETCH : (in_blas ? PW_WAIT : PW_ENTER);
+  s.state = take ? st : s.state;
 }
 
-// stackless jump: to the right child of pair `ref`, or off the end of the level
+// stackless jump: to the right child of pair `ref`; off the end of the level = whatever the stack holds next (in a BLAS:
+// the way out of the instance; on the TLAS level a stackless level has nothing stacked: the ray is done)
 RT_HD void pw_goto(PairLane& s, uint32_t ref) {
   s.curr = ref;
-  s.state = ref == RT_REF_END ? PW_LEVEL_END : PW_FETCHR;
+  s.state = ref == RT_REF_END ? PW_POP : PW_FETCHR;
 }
 
 // a new ray: the TLAS root is tested from its own record (two float4: {min, word} {max, -})
@@ -127,16 +143,13 @@ RT_HD void pw_begin(PairLane& s, bool active, bool any, rt3 o, rt3 d, float t_mi
   s.floor = 0u;
   s.resume = RT_REF_END;
   s.tlas_resume = RT_REF_END;
-  s.in_blas = false;
-  s.any = any;
-  s.found_any = false;
-  s.sl_tlas = false;
-  s.sl_blas = false;
+  s.flags = any ? PW_F_ANY : 0u;
   s.state = PW_DONE;
   if (active) {
     if (COUNT) n_nodes++;
     float a;
-    if (pw_box(rlx, rly, rlz, rhx, rhy, rhz, s.r, t_min, s.closest, a)) pw_child(s, rword, RT_REF_END);
+    const bool hit = pw_box(rlx, rly, rlz, rhx, rhy, rhz, s.r, t_min, s.closest, a);
+    pw_child(s, rword, RT_REF_END, hit);
   }
 }
 
@@ -152,100 +165,87 @@ RT_HD void pw_pair(PairLane& s, uint32_t self, float l0x, float l0y, float l0z, 
   bool hit_l = pw_box(l0x, l0y, l0z, l1x, l1y, l1z, s.r, t_min, s.closest, a_l);
   const bool hit_r = pw_box(r0x, r0y, r0z, r1x, r1y, r1z, s.r, t_min, s.closest, a_r);
   hit_l = hit_l && !only_r;
-  if (COUNT && !only_r) n_nodes++;            // L is reached now
-  bool sl = s.in_blas ? s.sl_blas : s.sl_tlas;
-  if (hit_l) {
-    // R is reached after L's subtree.  It passes later iff it passes now AND a_r <= the closest of that moment:
-    // tm_far = min(closest, far) only shrinks with closest, and a_r <= min(c_old, far) implies a_r <= far.
-    if (!sl && (hit_r || COUNT)) {
-      const uint32_t base = s.in_blas ? s.floor : 0u;
-      if (s.sp >= K) {            // overflow: this level drops its entries and goes on stackless
-        s.sp = base;
-        if (s.in_blas) s.sl_blas = true; else s.sl_tlas = true;
-        sl = true;
-      } else {
-        stk.push(s.sp, word_r, hit_r ? a_r : rt_u2f(0x7fc00000u));   // NaN: counted when popped, never entered
-        s.sp++;
-      }
-    }
-    pw_child(s, word_l, self);    // stackless successor of L's subtree: the right child of this very pair
-  } else {
-    if (COUNT) n_nodes++;         // R is reached now
-    if (hit_r) {
-      pw_child(s, word_r, skip_x);
-    } else if (sl) {
-      pw_goto(s, skip_x);
-    } else {
-      s.state = PW_POP;
-    }
+  if (COUNT) n_nodes += (only_r ? 0u : 1u) + (hit_l ? 0u : 1u);   // L is reached now; R too when L is not entered
+  const bool in_blas = pw_flag(s, PW_F_IN_BLAS);
+  bool sl = pw_flag(s, in_blas ? PW_F_SL_BLAS : PW_F_SL_TLAS);
+  // With L hit, R is reached after L's subtree.  It passes later iff it passes now AND a_r <= the closest of that moment:
+  // tm_far = min(closest, far) only shrinks with closest, and a_r <= min(c_old, far) implies a_r <= far.
+  const bool want_push = hit_l && !sl && (hit_r || COUNT);
+  const bool overflow = want_push && s.sp >= K;
+  const bool do_push = want_push && !overflow;
+  if (do_push) stk.push(s.sp, word_r, hit_r ? a_r : rt_u2f(0x7fc00000u));   // NaN: counted when popped, never entered
+  s.sp = do_push ? s.sp + 1u : s.sp;
+  if (overflow) {               // rare: this level drops its entries and goes on stackless
+    s.sp = in_blas ? s.floor : 0u;
+    s.flags |= in_blas ? PW_F_SL_BLAS : PW_F_SL_TLAS;
+    sl = true;
   }
+  const bool take = hit_l || hit_r;
+  // stackless successor of the child's subtree: after L the right child of this very pair, after R whatever follows the pair
+  pw_child(s, hit_l ? word_l : word_r, hit_l ? self : skip_x, take);
+  // nothing entered: the next pending entry, or (stackless) the node that follows the pair
+  const uint32_t jump = skip_x == RT_REF_END ? PW_POP : PW_FETCHR;
+  s.state = take ? s.state : (sl ? jump : PW_POP);
+  s.curr = (!take && sl) ? skip_x : s.curr;
 }
 
-// next pending right child (stack levels only).  STK: pop(slot, word&, a&)
+// next pending entry.  STK: pop(slot, word&, a&).  An empty stack ends the ray (a lane inside an instance always has at
+// least the entry's sentinel below it).  The sentinel: the BLAS is finished, back to the world-space ray and the TLAS level.
 template <bool COUNT, class STK>
 RT_HD void pw_pop(PairLane& s, STK& stk, uint32_t& n_nodes) {
-  const uint32_t base = s.in_blas ? s.floor : 0u;
-  if (s.sp <= base) {
-    s.state = PW_LEVEL_END;
-    return;
-  }
-  s.sp--;
+  const bool empty = s.sp == 0u;
+  s.sp = empty ? 0u : s.sp - 1u;
   uint32_t word;
   float a;
-  stk.pop(s.sp, word, a);
-  if (COUNT) n_nodes++;           // reached now
-  if (a <= s.closest) pw_child(s, word, RT_REF_END);   // `after` is never read: stack levels do not jump
-  // else: stays PW_POP
+  stk.pop(s.sp, word, a);       // (an empty lane reads slot 0 and ignores it)
+  const bool sent = !empty && word == RT_PW_SENTINEL;
+  const bool child = !empty && !sent;
+  if (COUNT) n_nodes += child ? 1u : 0u;          // a right child, reached now
+  const bool pass = child && a <= s.closest;
+  const bool sl_tlas = pw_flag(s, PW_F_SL_TLAS);
+  const bool more = sl_tlas ? (s.tlas_resume != RT_REF_END) : (s.sp != 0u);
+  if (sent && more) s.r = s.rw;
+  s.flags = sent ? (s.flags & ~(PW_F_IN_BLAS | PW_F_SL_BLAS)) : s.flags;
+  const uint32_t out_state = more ? (sl_tlas ? PW_FETCHR : PW_POP) : PW_DONE;
+  s.curr = (sent && sl_tlas) ? s.tlas_resume : s.curr;
+  s.state = empty ? PW_DONE : (sent ? out_state : s.state);   // a child that fails its re-test: stays PW_POP
+  pw_child(s, word, RT_REF_END, pass);            // `after` is never read: stack levels do not jump
 }
 
-// the level has nothing left: back to the TLAS, or the ray is finished
-RT_HD void pw_level_end(PairLane& s) {
-  if (s.in_blas) {
-    s.r = s.rw;
-    s.in_blas = false;
-    s.sl_blas = false;
-    if (s.sl_tlas) pw_goto(s, s.tlas_resume); else s.state = PW_POP;
-  } else {
-    s.state = PW_DONE;
-  }
-}
-
-// instance entry (Raytracer.wgsl:507-512): object-space ray, then the BLAS root from its own record
-template <bool COUNT>
+// instance entry (Raytracer.wgsl:507-512): object-space ray, the way out on the stack, then the BLAS root from its record
+template <bool COUNT, uint32_t K, class STK>
 RT_HD void pw_enter(PairLane& s, float m00, float m01, float m02, float m03, float m10, float m11, float m12, float m13,
                     float m20, float m21, float m22, float m23, float rlx, float rly, float rlz, uint32_t rword, float rhx,
-                    float rhy, float rhz, float t_min, uint32_t& n_nodes) {
+                    float rhy, float rhz, float t_min, STK& stk, uint32_t& n_nodes) {
   const rt3 o = s.rw.o, d = s.rw.d;
   rt3 lo = rt3_make(m00 * o.x + m01 * o.y + m02 * o.z + m03 * 1.0f, m10 * o.x + m11 * o.y + m12 * o.z + m13 * 1.0f,
                     m20 * o.x + m21 * o.y + m22 * o.z + m23 * 1.0f);
   rt3 ld = rt3_make(m00 * d.x + m01 * d.y + m02 * d.z + m03 * 0.0f, m10 * d.x + m11 * d.y + m12 * d.z + m13 * 0.0f,
                     m20 * d.x + m21 * d.y + m22 * d.z + m23 * 0.0f);
   s.r = pw_make_ray(lo, ld);
-  s.in_blas = true;
-  s.sl_blas = false;
+  const bool full = s.sp >= K;   // no room for the sentinel: the TLAS level drops its entries (only possible when the leaf came
+  s.sp = full ? 0u : s.sp;       // from a pair test, whose `after` is in tlas_resume: a popped leaf has just freed a slot)
+  s.flags = (s.flags | PW_F_IN_BLAS | (full ? PW_F_SL_TLAS : 0u)) & ~PW_F_SL_BLAS;
+  stk.push(s.sp, RT_PW_SENTINEL, 0.0f);
+  s.sp++;
   s.floor = s.sp;
   if (COUNT) n_nodes++;
   float a;
-  if (pw_box(rlx, rly, rlz, rhx, rhy, rhz, s.r, t_min, s.closest, a)) {
-    pw_child(s, rword, RT_REF_END);
-  } else {
-    s.state = PW_LEVEL_END;
-  }
+  const bool hit = pw_box(rlx, rly, rlz, rhx, rhy, rhz, s.r, t_min, s.closest, a);
+  s.state = PW_POP;             // a missed root: straight out again
+  pw_child(s, rword, RT_REF_END, hit);
 }
 
 // the leaf's triangles have been tested (trav flush): record the result, go on
 RT_HD void pw_after_leaf(PairLane& s, bool found, float t, uint32_t tri) {
-  if (found) {
-    if (s.any) {
-      s.found_any = true;
-      s.state = PW_DONE;
-      return;
-    }
-    s.closest = t;
-    s.best_tri = (int32_t)tri;
-    s.best_inst = (int32_t)s.cur_inst;
-  }
-  if (s.sl_blas) pw_goto(s, s.resume); else s.state = PW_POP;
+  const bool any = pw_flag(s, PW_F_ANY);
+  const bool keep = found && !any;
+  s.closest = keep ? t : s.closest;
+  s.best_tri = keep ? (int32_t)tri : s.best_tri;
+  s.best_inst = keep ? (int32_t)s.cur_inst : s.best_inst;
+  s.flags |= (found && any) ? PW_F_FOUND : 0u;
+  if (pw_flag(s, PW_F_SL_BLAS)) pw_goto(s, s.resume); else s.state = PW_POP;
+  s.state = (found && any) ? PW_DONE : s.state;
 }
 
 }  // namespace rtk

@@ -230,10 +230,10 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 // the records among more waves at the price of fewer waves per SIMD (LdsPlan, rt_api.hip plan_lds; measured without gain,
 // DESIGN.md 4.1b).  LDS = true: every traversal record fits (RT_TRAV_LDS).
 #ifndef RT_WF_WAVES
-#define RT_WF_WAVES 4   // waves per SIMD of the trace kernels: what the per-wave LDS block (work queue + stack, 8.3 KB at K = 8) leaves room for
+#define RT_WF_WAVES 5   // waves per SIMD of the trace kernels: what the per-wave LDS block (work queue + stack, 8.3 KB at K = 8) leaves room for
 #endif
 #ifndef RT_WF_STEPS_PER_TRIP
-#define RT_WF_STEPS_PER_TRIP 3   // RECORD fetches (two node tests each) between two looks at the ray queue and the triangle queue.
+#define RT_WF_STEPS_PER_TRIP 4   // RECORD fetches (two node tests each) between two looks at the ray queue and the triangle queue.
                                  // Round 2, single-node steps: first sweep on
                                  // sponza-like (ms per 32 frames): 1: 153.0, 2: 137.7, 3: 134.5, 4: 133.2, 6: 132.0, 8: 131.4.
                                  // Final kernels, (steps, refill) -> ms per frame sponza-like / instanced x1000 / glass blob 4K:
@@ -244,9 +244,151 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
 // sections of the trace loop, summed over all waves of all launches: [ANY][0..2] = cycles in retire/pull, node step,
 // triangle flush; [3..5] = how often each section did work; [6] = waves; [7] = loop trips.  Nothing else reads it.
 __device__ unsigned long long g_trace_sections[2][8];
+// ---- walk over single nodes (rounds 1-2): kept behind rt_set_walk / MI355RT_WALK=node for A/B measurements
+#ifndef RT_WF_NODE_WAVES
+#define RT_WF_NODE_WAVES 6
+#endif
+#ifndef RT_WF_NODE_STEPS_PER_TRIP
+#define RT_WF_NODE_STEPS_PER_TRIP 6
+#endif
+template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_NODE_WAVES) : (BLOCK == 512 ? 2 : 4))
+void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
+                uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
+  extern __shared__ f4 s_scene[];
+  WaveWork W;
+  char* const wbase = reinterpret_cast<char*>(s_scene) + (threadIdx.x >> 6) * RT_WORK_BYTES_PER_WAVE;
+  wave_work_at(W, wbase);
+  const uint32_t rec0 = ((BLOCK / 64) * RT_WORK_BYTES_PER_WAVE) / 16;
+  TravMem M;
+  if (LDS) {
+    LdsPlan all;
+    all.k_nodes = n_nodes_total;
+    all.stage_inst = all.stage_tri = 1u;
+    all.pad = 0u;
+    trav_stage_mixed(M, s_scene, rec0, Sg, all, n_tris_total, n_inst_total);
+  } else {
+    trav_stage_mixed(M, s_scene, rec0, Sg, plan, n_tris_total, n_inst_total);
+  }
+  __syncthreads();
+  constexpr int MODE = LDS ? RT_TRAV_LDS : RT_TRAV_MIXED;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t blas_base = U.blas_base_idx;
+  uint32_t* cnt = Q.counters + 8u * depth;
+  const uint32_t n_rays = ANY ? cnt[1] : cnt[2];
+  uint32_t* head = ANY ? &cnt[3] : &cnt[4];
+  const uint32_t* ids = ANY ? Q.shadow_ids : Q.ext_ids;
+  const float4* rays = ANY ? Q.shadow_rays : Q.ext_rays[depth & 1u];
+
+  // per-lane ray + traversal state
+  bool have_ray = false;
+  uint32_t slot = 0u;
+  Trav s;
+  trav_begin(s, false, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), 0.0f);
+  bool queue_left = true;
+  uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
+  uint32_t n_nodes = 0, n_tris = 0, n_traced = 0;
+
+#ifdef RT_TRACE_STAMPS
+  unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
+#endif
+  for (;;) {
+#ifdef RT_TRACE_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    st_trips++;
+#endif
+    // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
+    const bool done = have_ray && !s.searching && !s.waiting;
+    const bool idle = !have_ray || done;
+    const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
+    const unsigned long long busy_m = __ballot(s.searching || s.waiting);
+    if (idle_m != 0ull &&
+        ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
+         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+#ifdef RT_TRACE_STAMPS
+      st_cnt[0]++;
+#endif
+      if (done) {
+        if (ANY)
+          Q.occluded[slot] = s.any ? 1u : 0u;
+        else
+          Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
+        have_ray = false;
+      }
+      // pull: needy lanes take consecutive entries of the wave's chunk; a new chunk costs one atomic
+      const bool need = !have_ray;
+      const unsigned long long need_m = __ballot(need);
+      if (queue_left && need_m != 0ull) {
+        if (chunk_pos >= chunk_end) {
+          uint32_t bq = 0;
+          if (lane == 0u) bq = atomicAdd(head, RT_WF_CHUNK);
+          bq = __shfl(bq, 0, 64);
+          if (bq >= n_rays) {
+            queue_left = false;
+          } else {
+            chunk_pos = bq;
+            chunk_end = bq + RT_WF_CHUNK < n_rays ? bq + RT_WF_CHUNK : n_rays;
+          }
+        }
+        if (queue_left) {
+          const uint32_t rank =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(need_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_m, 0u));
+          const uint32_t qi = chunk_pos + rank;
+          chunk_pos += (uint32_t)__builtin_popcountll(need_m);
+          if (need && qi < chunk_end && ids[qi] != RT_WF_INVALID) {
+            const float4 r0 = rays[2 * qi], r1 = rays[2 * qi + 1];
+            slot = qi;
+            n_traced++;
+            have_ray = true;
+            trav_begin(s, true, blas_base, xyz(r0), xyz(r1), ANY ? r0.w : RT_T_MAX);
+          }
+        }
+      }
+    }
+    if (!queue_left && __ballot(have_ray) == 0ull) break;  // queue exhausted and every ray retired
+
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+    st_cyc[0] += st1 - st0;
+    if (__ballot(s.searching) != 0ull) st_cnt[1]++;
+#endif
+    trav_trip<DETAIL, MODE, RT_WF_NODE_STEPS_PER_TRIP>(M, s_scene, s, n_nodes);
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    st_cyc[1] += st2 - st1;
+    const bool was_waiting = __ballot(s.waiting) != 0ull;
+#endif
+    trav_flush<ANY, DETAIL, MODE>(M, s_scene, W, s, n_tris);
+#ifdef RT_TRACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    st_cyc[2] += __builtin_amdgcn_s_memtime() - st2;
+    if (was_waiting && __ballot(s.waiting) == 0ull) st_cnt[2]++;
+#endif
+  }
+#ifdef RT_TRACE_STAMPS
+  if (lane == 0u) {
+    for (int k = 0; k < 3; k++) {
+      atomicAdd(&g_trace_sections[ANY ? 1 : 0][k], st_cyc[k]);
+      atomicAdd(&g_trace_sections[ANY ? 1 : 0][3 + k], st_cnt[k]);
+    }
+    atomicAdd(&g_trace_sections[ANY ? 1 : 0][6], 1ull);
+    atomicAdd(&g_trace_sections[ANY ? 1 : 0][7], st_trips);
+  }
+#endif
+  LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};
+  flush_counters<DETAIL>(c, F.counters, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+}
+
+// ---- walk over child-pair records (round 3, k_pairwalk.hip.h / k_pairtrav.hip.h)
+#ifndef RT_WF_PAIR_REFILL
+#define RT_WF_PAIR_REFILL 16   // idle lanes that trigger a pull (swept 8 / 12 / 16 / 24 / 32 on the 263 k-triangle hall, ms per
+                               // 32-frame batch: 181.3 / 179.6 (one pop per round) / 181.6 / 187.0 / 226.9)
+#endif
 template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_WAVES) : (BLOCK == 512 ? 2 : 4))
-void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_pairs_total,
+void k_wf_trace_pairs(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_pairs_total,
                 uint32_t n_tris_total, uint32_t n_inst_total, PairPlan plan) {
   extern __shared__ f4 s_scene[];
   WaveWork W;
@@ -256,9 +398,8 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   const uint32_t rec0 = ((BLOCK / 64) * RT_PW_BYTES_PER_WAVE) / 16;
   PairMem M;
   if (LDS) {
-    PairPlan all;
+    PairPlan all = plan;
     all.stage_pairs = all.stage_inst = all.stage_tri = 1u;
-    all.pad = 0u;
     pw_stage(M, s_scene, rec0, Sg, all, n_pairs_total, n_tris_total, n_inst_total, RT_T_MIN);
   } else {
     pw_stage(M, s_scene, rec0, Sg, plan, n_pairs_total, n_tris_total, n_inst_total, RT_T_MIN);
@@ -280,6 +421,9 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
   pw_start<false>(M, s, false, ANY, blas_base, rt3_splat(1.0f), rt3_splat(1.0f), 0.0f, n_nodes);
   bool queue_left = true;
   uint32_t chunk_pos = 0u, chunk_end = 0u;  // wave-uniform cursor into the chunk of the input queue this wave holds
+#ifdef RT_PW_STAMPS
+  unsigned long long pw_cyc[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
 #ifdef RT_TRACE_STAMPS
   unsigned long long st_cyc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_trips = 0;
@@ -295,14 +439,14 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
     const unsigned long long busy_m = __ballot(s.state != PW_DONE);
     if (idle_m != 0ull &&
-        ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
-         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
+        ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_PAIR_REFILL ||
+         (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_PAIR_REFILL) || busy_m == 0ull)) {
 #ifdef RT_TRACE_STAMPS
       st_cnt[0]++;
 #endif
       if (done) {
         if (ANY)
-          Q.occluded[slot] = s.found_any ? 1u : 0u;
+          Q.occluded[slot] = pw_flag(s, PW_F_FOUND) ? 1u : 0u;
         else
           Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
         have_ray = false;
@@ -345,7 +489,11 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     st_cyc[0] += st1 - st0;
     if (__ballot(pw_can_step(s)) != 0ull) st_cnt[1]++;
 #endif
-    pw_trip<DETAIL, LDS, RT_WF_STEPS_PER_TRIP>(M, s_scene, stk, s, n_nodes);
+#ifdef RT_PW_STAMPS
+    pw_trip<DETAIL, LDS, RT_WF_STEPS_PER_TRIP>(M, s_scene, reinterpret_cast<f4*>(wbase), stk, s, n_nodes, pw_cyc);
+#else
+    pw_trip<DETAIL, LDS, RT_WF_STEPS_PER_TRIP>(M, s_scene, reinterpret_cast<f4*>(wbase), stk, s, n_nodes);
+#endif
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
@@ -367,6 +515,12 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     }
     atomicAdd(&g_trace_sections[ANY ? 1 : 0][6], 1ull);
     atomicAdd(&g_trace_sections[ANY ? 1 : 0][7], st_trips);
+  }
+#endif
+#ifdef RT_PW_STAMPS
+  if (lane == 0u) {
+    for (int k = 0; k < 6; k++) atomicAdd(&g_trace_sections[ANY ? 1 : 0][k], pw_cyc[k]);
+    atomicAdd(&g_trace_sections[ANY ? 1 : 0][6], 1ull);
   }
 #endif
   LaneCounters c = {0, ANY ? 0u : n_traced, ANY ? n_traced : 0u, n_nodes, n_tris, 0};

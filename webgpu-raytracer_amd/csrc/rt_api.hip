@@ -67,6 +67,7 @@ struct rt_ctx {
   DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w, treelet_work;   // k_treelet.hip.h
   DeviceBuffer pairs, pair_of, pair_parent, root_rec;                             // k_pairs.hip.h
   uint32_t n_pairs = 0;             // inner nodes of the uploaded TLAS ++ BLAS arrays (counted on the host at upload)
+  rtk::TlasRoot troot = {};         // box and word of the TLAS root (node 0), passed to the trace kernels by value
   bool roots_dirty = true;          // root records: rebuilt on every instance upload (cheap); the pair records only when the
                                     // node array or the SET of BLAS roots changed
   std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
@@ -105,7 +106,10 @@ struct rt_ctx {
   int occ_blocks[4] = {0, 0, 0, 0};   // cached occupancy query per persistent-kernel variant
   int wf_occ_blocks[2] = {0, 0};      // ... and for the two wavefront trace kernels
   size_t wf_occ_dyn = (size_t)-1;
-  int wf_occ_detail = -1, wf_occ_block = 0;
+  int wf_occ_detail = -1, wf_occ_block = 0, wf_occ_walk = -1;
+  int walk = 2;                  // traversal of the wavefront trace kernels: 1 = child-pair records, 0 = single nodes, 2 = auto
+                                 // (MI355RT_WALK): pairs for a scene of ONE instance (measured: the 263 k-triangle hall -9 % per
+                                 // batch; glass blob, 2 instances and short walks: +7 %; 1 001 instances of 8 triangles: +20 %)
   int wf_blocks_per_cu = 0;      // 0 = default for the block size (MI355RT_WF_BLOCKS_PER_CU)
   long treelet_cap = -1;
   size_t occ_dyn[4] = {0, 0, 0, 0};
@@ -495,6 +499,7 @@ rt_ctx* rt_create(int device_ordinal) {
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
   }
   if (const char* e = getenv("MI355RT_TREELET_MAX")) c->treelet_cap = atol(e);
+  if (const char* e = getenv("MI355RT_WALK")) c->walk = (e[0] == 'n' || e[0] == '0') ? 0 : ((e[0] == 'a' || e[0] == '2') ? 2 : 1);   // node / pairs / auto
   if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
     const int b = atoi(e);
     if (b >= 1 && b <= 8) c->wf_blocks_per_cu = b;
@@ -944,6 +949,14 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
     for (uint32_t k = 0; k < n_tlas; k++) inner += tw[8 * (size_t)k + 7] == 0u;
     for (uint32_t k = 0; k < n_blas; k++) inner += bw[8 * (size_t)k + 7] == 0u;
     c->n_pairs = inner;
+    std::memset(&c->troot, 0, sizeof(c->troot));
+    if (n_tlas) {   // node 0; an inner root is the first inner node of the array: pair record 0
+      for (int k = 0; k < 3; k++) {
+        c->troot.lo[k] = tlas[k];
+        c->troot.hi[k] = tlas[4 + k];
+      }
+      c->troot.word = tw[7] == 0u ? RT_PAIR_INNER : tw[7];
+    }
   }
   c->roots_dirty = true;
   c->validate_dirty = true;
@@ -1038,6 +1051,17 @@ static const void* wf_trace_fn(bool any, bool detail, bool lds) {
   return lds ? (const void*)rtk::k_wf_trace<false, false, true, BLOCK> : (const void*)rtk::k_wf_trace<false, false, false, BLOCK>;
 }
 }  // extern "C++"
+extern "C++" {
+template <int BLOCK>
+static const void* wf_trace_pairs_fn(bool any, bool detail, bool lds) {
+  if (any) {
+    if (detail) return lds ? (const void*)rtk::k_wf_trace_pairs<true, true, true, BLOCK> : (const void*)rtk::k_wf_trace_pairs<true, true, false, BLOCK>;
+    return lds ? (const void*)rtk::k_wf_trace_pairs<true, false, true, BLOCK> : (const void*)rtk::k_wf_trace_pairs<true, false, false, BLOCK>;
+  }
+  if (detail) return lds ? (const void*)rtk::k_wf_trace_pairs<false, true, true, BLOCK> : (const void*)rtk::k_wf_trace_pairs<false, true, false, BLOCK>;
+  return lds ? (const void*)rtk::k_wf_trace_pairs<false, false, true, BLOCK> : (const void*)rtk::k_wf_trace_pairs<false, false, false, BLOCK>;
+}
+}  // extern "C++"
 
 // Wavefront form: per depth one shade launch and two trace launches, all enqueued without host readback.
 static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, const DevFrameSlot* dslots, uint32_t n,
@@ -1074,40 +1098,79 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   Q.occluded = (uint32_t*)(qb + qcap * 128);
   Q.counters = (uint32_t*)c->wf_counters.ptr;
   const bool detail = c->detailed_counters;
-  // Workgroup shape of the trace kernels.  Every wave owns RT_PW_BYTES_PER_WAVE of LDS (triangle work queue + the stack of
-  // deferred right children).  Everything fits beside four wave blocks in 64 KB: 256-thread workgroups, all records in
-  // LDS.  Otherwise 256-thread workgroups, as many per CU as the wave blocks allow (4 at K = 8), each staging what fits
-  // whole in its share of the LDS (plan_pairs); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
-  const size_t lds_records = ((size_t)4 * c->n_pairs + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)6 * c->n_instances) * 16;
-  const bool trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_PW_BYTES_PER_WAVE <= 64 * 1024;
+  const bool pairs = c->walk == 1 || (c->walk == 2 && c->n_instances == 1);   // rt_set_walk
   int block = 256, blocks_per_cu = 0;
-  if (!trace_lds) {
-    block = c->wf_block ? c->wf_block : 256;
-    const int fit = (int)(c->lds_per_cu / ((size_t)(block / 64) * RT_PW_BYTES_PER_WAVE));
-    blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : std::max(1, std::min(fit, (RT_WF_WAVES * 256) / block));
-  }
-  const size_t queue_bytes = (size_t)(block / 64) * RT_PW_BYTES_PER_WAVE;
-  size_t dyn = queue_bytes + lds_records;
+  size_t dyn = 0;
+  bool trace_lds = false;
   rtk::PairPlan plan;
-  plan.stage_pairs = plan.stage_inst = plan.stage_tri = 1;
-  plan.pad = 0;
-  if (!trace_lds) plan = plan_pairs(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+  rtk::LdsPlan nplan;
   const void* trace_fn[2];
-  for (int k = 0; k < 2; k++)
-    trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds)
-                                : (block == 512 ? wf_trace_fn<512>(k == 0, detail, trace_lds) : wf_trace_fn<256>(k == 0, detail, trace_lds));
-  if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_blocks[0] == 0) {
-    for (int k = 0; k < 2; k++) {
-      HIP_TRY(c, hipFuncSetAttribute(trace_fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      int per_cu = 0;
-      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], block, dyn));
-      c->wf_occ_blocks[k] = per_cu < 1 ? 1 : per_cu;
+  if (pairs) {
+    // Workgroup shape of the trace kernels.  Every wave owns RT_PW_BYTES_PER_WAVE of LDS (triangle work queue + the stack of
+    // deferred right children).  Everything fits beside four wave blocks in 64 KB: 256-thread workgroups, all records in
+    // LDS.  Otherwise 256-thread workgroups, as many per CU as the wave blocks allow (4 at K = 8), each staging what fits
+    // whole in its share of the LDS (plan_pairs); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
+    const size_t lds_records = ((size_t)4 * c->n_pairs + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)6 * c->n_instances) * 16;
+    trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_PW_BYTES_PER_WAVE <= 64 * 1024;
+    if (!trace_lds) {
+      block = c->wf_block ? c->wf_block : 256;
+      const int fit = (int)(c->lds_per_cu / ((size_t)(block / 64) * RT_PW_BYTES_PER_WAVE));
+      blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : std::max(1, std::min(fit, (RT_WF_WAVES * 256) / block));
     }
-    c->wf_occ_dyn = dyn;
-    c->wf_occ_detail = (int)detail;
-    c->wf_occ_block = block;
+    const size_t queue_bytes = (size_t)(block / 64) * RT_PW_BYTES_PER_WAVE;
+    dyn = queue_bytes + lds_records;
+    plan.stage_pairs = plan.stage_inst = plan.stage_tri = 1;
+    plan.pad = 0;
+    if (!trace_lds) plan = plan_pairs(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+    plan.troot = c->troot;
+    for (int k = 0; k < 2; k++)
+      trace_fn[k] = block == 1024 ? wf_trace_pairs_fn<1024>(k == 0, detail, trace_lds)
+                                  : (block == 512 ? wf_trace_pairs_fn<512>(k == 0, detail, trace_lds) : wf_trace_pairs_fn<256>(k == 0, detail, trace_lds));
+    if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_walk != (int)pairs || c->wf_occ_blocks[0] == 0) {
+      for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipFuncSetAttribute(trace_fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        int per_cu = 0;
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], block, dyn));
+        c->wf_occ_blocks[k] = per_cu < 1 ? 1 : per_cu;
+      }
+      c->wf_occ_dyn = dyn;
+      c->wf_occ_detail = (int)detail;
+      c->wf_occ_block = block;
+      c->wf_occ_walk = (int)pairs;
+    }
+  } else {
+    // Workgroup shape of the trace kernels.  Everything fits beside four wave queues in 64 KB: 256-thread workgroups, all
+    // records in LDS.  Otherwise six 256-thread workgroups per CU (6 waves per SIMD), each staging what fits whole in its
+    // sixth of the LDS (plan_lds); MI355RT_WF_BLOCK / MI355RT_WF_BLOCKS_PER_CU override the shape for sweeps.
+    const size_t lds_records = ((size_t)2 * c->n_nodes + (size_t)RT_TRI_STRIDE * c->n_tris + (size_t)4 * c->n_instances + ((size_t)c->n_instances + 3) / 4) * 16;
+    trace_lds = !c->no_lds_staging && fits_lds && lds_records + (size_t)4 * RT_WORK_BYTES_PER_WAVE <= 64 * 1024;
+    if (!trace_lds) {
+      block = c->wf_block ? c->wf_block : 256;
+      blocks_per_cu = c->wf_blocks_per_cu ? c->wf_blocks_per_cu : (block == 1024 ? 1 : (block == 512 ? 2 : 6));
+    }
+    const size_t queue_bytes = (size_t)(block / 64) * RT_WORK_BYTES_PER_WAVE;
+    dyn = queue_bytes + lds_records;
+    nplan.k_nodes = c->n_nodes;
+    nplan.stage_inst = nplan.stage_tri = 1;
+    nplan.pad = 0;
+    if (!trace_lds) nplan = plan_lds(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+    for (int k = 0; k < 2; k++)
+      trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds)
+                                  : (block == 512 ? wf_trace_fn<512>(k == 0, detail, trace_lds) : wf_trace_fn<256>(k == 0, detail, trace_lds));
+    if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_walk != (int)pairs || c->wf_occ_blocks[0] == 0) {
+      for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipFuncSetAttribute(trace_fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        int per_cu = 0;
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_fn[k], block, dyn));
+        c->wf_occ_blocks[k] = per_cu < 1 ? 1 : per_cu;
+      }
+      c->wf_occ_dyn = dyn;
+      c->wf_occ_detail = (int)detail;
+      c->wf_occ_block = block;
+      c->wf_occ_walk = (int)pairs;
+    }
   }
-  uint32_t nn = c->n_pairs, nt = c->n_tris, ni = c->n_instances;
+  uint32_t nn = pairs ? c->n_pairs : c->n_nodes, nt = c->n_tris, ni = c->n_instances;
   EventPair* ev = next_events(c, RT_TIMER_PATHTRACE);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
   for (uint32_t depth = 0; depth < depths; depth++) {
@@ -1132,7 +1195,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       DevScene Sa = S;
       DevFrame Fa = F;
       rt_scene_uniforms Ua = c->uniforms;
-      void* args[] = {&Sa, &Fa, &Ua, &Q, &depth, &nn, &nt, &ni, &plan};
+      void* args[] = {&Sa, &Fa, &Ua, &Q, &depth, &nn, &nt, &ni, pairs ? (void*)&plan : (void*)&nplan};
       EventPair* evt = next_events(c, k == 0 ? RT_TIMER_WF_TRACE_SHADOW : RT_TIMER_WF_TRACE_EXT);
       hipStream_t st = c->stream;
       if (k == 0 && c->wf_overlap) {   // any-hit trace: fork to the side stream behind this depth's shade kernel
@@ -1512,6 +1575,11 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
 int rt_set_kernel_variant(rt_ctx* c, int variant) {
   if (!c || variant < 0 || variant > 3) return RT_ERR_INVALID;
   c->variant = variant;
+  return RT_OK;
+}
+int rt_set_walk(rt_ctx* c, int walk) {
+  if (!c || walk < 0 || walk > 2) return RT_ERR_INVALID;
+  c->walk = walk;
   return RT_OK;
 }
 int rt_set_kernel_timing(rt_ctx* c, int enabled) {
