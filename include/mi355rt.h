@@ -174,6 +174,14 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Average duration in ms of the path-trace kernel over the launches since the last call
  * (HIP events recorded on the context stream around each launch); also returns the launch count. */
 int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary_ms, uint32_t* launches);
+/* Speculative lookahead for the live loop (src/main.ts:168-173: compute(frameCount); present() per displayed frame).  With
+ * max_frames > 1, a compute(f) that continues a run of consecutive frame counts traces the frames f .. f+L-1 as ONE batched
+ * dispatch (L doubles along the run, up to max_frames <= 64) and accumulates only frame f; the compute(f+1) ... that follow
+ * find their frame ready and only add it.  Images, G-buffer read-backs and the accumulation buffer are bit for bit those of
+ * one dispatch per frame; any call that changes what a frame looks like (uploads, rt_set_scene, rt_resize, rt_set_pipeline,
+ * ...) drops what was traced ahead.  While it is on, the ray counters count a frame when it is TRACED (ahead of its compute()
+ * call), and the detailed-counter build does not trace ahead.  0 (default) / 1 = off. */
+int rt_set_lookahead(rt_ctx* ctx, uint32_t max_frames);
 /* Traversal of the wavefront trace kernels: 1 = child-pair records (csrc/k_pairwalk.hip.h: one 64-byte record per inner
  * node, both children tested per fetch, quad-cooperative LDS-DMA fetch, short per-lane stack); 0 = one 32-byte node per step
  * with skip pointers only (rounds 1-2); 2 (default) = auto: pairs for a scene of one instance, nodes otherwise (where each

@@ -618,3 +618,42 @@ def test_pair_records_equal_the_numpy_restatement(W, gpu_renderer, scene):
     assert np.array_equal(got_pairs[:n].view(np.uint32), pairs.view(np.uint32))
     assert np.array_equal(got_roots[:-1].view(np.uint32), inst_root.view(np.uint32))
     assert np.array_equal(got_roots[-1].view(np.uint32), troot.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene,w,h,depth", [("cornell", 96, 72, 6), ("instanced1000", 64, 36, 8)])
+def test_lookahead_live_loop_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth):
+    """rt_set_lookahead: consecutive compute(f); present() calls are traced ahead as batches (1, 2, 4, 8, ... frames).  Every
+    frame's accumulation buffer, G-buffer and presented image must be those of one dispatch per frame — checked against the
+    oracle after frames in the middle of a traced-ahead batch, across a camera change (which drops what was traced ahead)
+    and across a restart of the frame count."""
+    b = pu.bridge_for(W, scene)
+    cpu = oracle_lib.OracleRenderer()
+    gpu_renderer.setLookahead(16)
+    for r in (gpu_renderer, cpu):
+        r.buildPipeline(depth, 1)
+        W.upload_scene(r, b, w, h)
+
+    def frames(lo, hi, present):
+        for r in (gpu_renderer, cpu):
+            for f in range(lo, hi + 1):
+                r.compute(f)
+                if present:
+                    r.present()
+            r.sync()
+
+    frames(1, 6, True)             # dispatches of 1, 2 (2-3), 4 (4-7) frames: frame 6 sits inside a batch
+    pu.assert_parity(gpu_renderer, cpu, check_output=True, check_counters=False)
+    frames(7, 11, False)           # 7 consumed, 8-15 traced ahead, 11 consumed
+    pu.assert_parity(gpu_renderer, cpu, check_output=False, check_counters=False)   # includes the G-buffer of frame 11
+    cam = np.array(b.cameraData, dtype=np.float32).copy()
+    cam[0] += 0.05                 # the camera moves: frames 12-15 traced ahead are stale and must not be used
+    for r in (gpu_renderer, cpu):
+        r.updateSceneUniforms(cam, 0, b.lightCount)
+        r.resetAccumulation()
+    frames(1, 9, True)
+    pu.assert_parity(gpu_renderer, cpu, check_output=True, check_counters=False)
+    for r in (gpu_renderer, cpu):  # frame count restarts without any other change: not a continuation
+        r.resetAccumulation()
+    frames(1, 3, False)
+    pu.assert_parity(gpu_renderer, cpu, check_output=False, check_counters=False)
+    gpu_renderer.setLookahead(0)

@@ -122,6 +122,26 @@ struct rt_ctx {
   hipEvent_t slot_ring_ev[kSlotRing] = {};
   bool slot_ring_used[kSlotRing] = {};
   int slot_ring_next = 0;
+  // Speculative lookahead of the live loop (rt_set_lookahead): a compute(f) that continues a run f-1, f traces the frames
+  // f .. f+L-1 as ONE batched dispatch (L doubles while the run goes on) and accumulates only frame f; the following
+  // compute(f+1) ... find their frame colours ready and only add them.  Any call that changes what a frame looks like
+  // bumps `epoch` and drops what was traced ahead.
+  uint32_t lookahead_max = 0;       // 0 / 1: off
+  uint64_t epoch = 0;
+  struct {
+    bool valid = false;
+    uint64_t epoch = 0;
+    uint32_t n = 0, k = 0;          // frames traced, frames consumed
+    uint32_t fc0 = 0, tf0 = 0;      // frame_count / totalFrames of the first traced frame
+    const DevFrameSlot* dslots = nullptr;
+    std::vector<DevFrameSlot> slots;   // host copy (jitter check, G-buffer planes of each frame)
+    DevFrame frame;
+  } spec;
+  uint32_t run_len = 0, run_last_fc = 0, run_last_tf = 0;   // the run of consecutive single-frame compute() calls
+  uint64_t run_epoch = 0;
+  uint32_t look = 1;                // frames the next dispatch of the run traces
+  int gbuf_slot = -1;               // >= 0: the last compute() consumed this frame of the traced batch (rt_read_gbuffer)
+  uint32_t acc_frames = 0;          // frames k_accumulate_frames adds at the end of a dispatch (all of them unless traced ahead)
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
   DeviceBuffer frame_col;   // per-frame colours of a batch, added in frame order by k_accumulate_frames
   DeviceBuffer wf_state, wf_queues, wf_counters;  // wavefront form: path state, ray / path queues, queue counters
@@ -559,6 +579,7 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->error.c_str() : g_cre
 
 int rt_set_pipeline(rt_ctx* c, uint32_t max_depth, uint32_t spp) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (spp == 0) return fail(c, RT_ERR_INVALID, "SPP must be >= 1");
   c->max_depth = max_depth;
   c->spp = spp;
@@ -568,6 +589,7 @@ int rt_set_pipeline(rt_ctx* c, uint32_t max_depth, uint32_t spp) {
 
 int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
     return fail(c, RT_ERR_INVALID, "invalid screen size");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -609,6 +631,7 @@ int rt_reset_accum(rt_ctx* c) {
 
 int rt_upload_textures(rt_ctx* c, const uint8_t* rgba, uint32_t layers) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   HIP_TRY(c, hipSetDevice(c->device));
   if (layers == 0) {
     c->tex_layers = 0;
@@ -628,6 +651,7 @@ int rt_upload_textures(rt_ctx* c, const uint8_t* rgba, uint32_t layers) {
 
 int rt_alloc_texture_layers(rt_ctx* c, uint32_t layers) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   HIP_TRY(c, hipSetDevice(c->device));
   if (layers == 0) {
     c->tex_layers = 0;
@@ -646,6 +670,7 @@ int rt_alloc_texture_layers(rt_ctx* c, uint32_t layers) {
 
 int rt_upload_texture_image(rt_ctx* c, uint32_t layer, const uint8_t* rgba, uint32_t width, uint32_t height) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (layer >= c->tex_layers || !c->textures.ptr) return fail(c, RT_ERR_INVALID, "texture layer out of range");
   if (rgba && (width == 0 || height == 0 || width > 32768u || height > 32768u))
     return fail(c, RT_ERR_INVALID, "texture image size out of range");
@@ -833,6 +858,7 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
 
 int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (bytes && !data) return fail(c, RT_ERR_INVALID, "null data");
   HIP_TRY(c, hipSetDevice(c->device));
   int r;
@@ -909,6 +935,7 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
 
 int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const float* uv2, uint32_t vertex_count) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (vertex_count && (!pos4 || !nrm4 || !uv2)) return fail(c, RT_ERR_INVALID, "null geometry array");
   HIP_TRY(c, hipSetDevice(c->device));
   // The reference packs the three arrays into one buffer at 256-byte aligned offsets because WebGPU
@@ -929,6 +956,7 @@ int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const fl
 
 int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* blas, uint32_t n_blas) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if ((n_tlas && !tlas) || (n_blas && !blas)) return fail(c, RT_ERR_INVALID, "null BVH array");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t total = ((size_t)n_tlas + n_blas) * sizeof(rt_node);
@@ -967,6 +995,7 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
 
 int rt_set_scene(rt_ctx* c, const float camera[24], uint32_t frame_count, uint32_t light_count) {
   if (!c || !camera) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   c->light_count = light_count;
   step_jitter(c, frame_count, frame_count);
   std::memcpy(&c->uniforms.camera, camera, 96);
@@ -1223,17 +1252,27 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
   }
   if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
-  hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots, n,
+  hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots, c->acc_frames,
                      c->width, c->height);
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
 }
 
 // compute() for n consecutive frame counts in ONE dispatch of each kernel (n == 1: the plain compute()).
-static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
-  if (!c || !frame_counts || n == 0) return RT_ERR_INVALID;
+// n_commit < n: frames n_commit .. n-1 are traced AHEAD (speculative lookahead): their host state is not committed and their
+// colours are not accumulated yet — consume_ahead() does both when the matching compute() call arrives.
+static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n, uint32_t n_commit) {
+  if (!c || !frame_counts || n == 0 || n_commit == 0 || n_commit > n) return RT_ERR_INVALID;
+  c->spec.valid = false;   // whatever was traced ahead is dropped: its buffers are about to be reused
+  c->gbuf_slot = -1;
   // host state advances exactly as n successive compute() calls would (WebGPURenderer.ts:88-91)
   std::vector<DevFrameSlot> slots(n);
+  const uint32_t tf_first = c->total_frames + 1;
+  struct HostState {
+    uint32_t total_frames;
+    double jx, jy, acc_jx, acc_jy, avg_jx, avg_jy;
+    rt_scene_uniforms uniforms;
+  } committed = {};
   for (uint32_t i = 0; i < n; i++) {
     c->total_frames++;
     step_jitter(c, c->total_frames, frame_counts[i]);  // updateFrameUniforms(frameCount, totalFrames)
@@ -1243,7 +1282,17 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     slots[i].jitter_y = c->uniforms.jitter[1];
     slots[i].pad = 0;
     slots[i].pad2 = 0;
+    if (i + 1 == n_commit) committed = {c->total_frames, c->jx, c->jy, c->acc_jx, c->acc_jy, c->avg_jx, c->avg_jy, c->uniforms};
   }
+  // the renderer's host state is that of the committed frames only
+  const rt_scene_uniforms launch_uniforms = c->uniforms;
+  (void)launch_uniforms;
+  c->total_frames = committed.total_frames;
+  c->jx = committed.jx; c->jy = committed.jy;
+  c->acc_jx = committed.acc_jx; c->acc_jy = committed.acc_jy;
+  c->avg_jx = committed.avg_jx; c->avg_jy = committed.avg_jy;
+  c->uniforms = committed.uniforms;
+  c->acc_frames = n_commit;
   if (!scene_ready(c)) return RT_SKIPPED;
   if (c->accum_stale)
     return fail(c, RT_ERR_INVALID, "the bound accumulation buffer was dropped by rt_resize: call rt_bind_accum again");
@@ -1401,20 +1450,85 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
     if (ev) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     if (n > 1)  // ordered accumulation of the batch's frame colours
       hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, dslots,
-                         n, c->width, c->height);
+                         c->acc_frames, c->width, c->height);
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(c->slot_ring_ev[ring], c->stream));
   c->slot_ring_used[ring] = true;
+  if (n_commit < n) {   // frames traced ahead: remember where their colours and G-buffers are
+    c->spec.valid = true;
+    c->spec.epoch = c->epoch;
+    c->spec.n = n;
+    c->spec.k = n_commit;
+    c->spec.fc0 = frame_counts[0];
+    c->spec.tf0 = tf_first;
+    c->spec.dslots = dslots;
+    c->spec.slots = slots;
+    c->spec.frame = F;
+    c->gbuf_slot = (int)n_commit - 1;
+  }
   return RT_OK;
 }
 
-int rt_compute(rt_ctx* c, uint32_t frame_count) { return compute_frames(c, &frame_count, 1); }
+// compute(frame_count) when that frame has been traced ahead: commit its host state, add its colours.
+static int consume_ahead(rt_ctx* c, uint32_t frame_count) {
+  auto& sp = c->spec;
+  const uint32_t k = sp.k;
+  c->total_frames++;
+  step_jitter(c, c->total_frames, frame_count);
+  write_mixed(c, frame_count);
+  if (c->uniforms.jitter[0] != sp.slots[k].jitter_x || c->uniforms.jitter[1] != sp.slots[k].jitter_y)
+    return fail(c, RT_ERR_INTERNAL, "lookahead: the frame traced ahead does not match the frame asked for");
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevFrame F = sp.frame;
+  const size_t npx = (size_t)c->width * c->height;
+  F.accum = accum_ptr(c);
+  F.frame_col = sp.frame.frame_col + (size_t)k * npx;
+  hipLaunchKernelGGL(rtk::k_accumulate_frames, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, c->stream, F, sp.dslots + k, 1u,
+                     c->width, c->height);
+  HIP_TRY(c, hipGetLastError());
+  c->gbuf_slot = (int)k;
+  sp.k++;
+  if (sp.k >= sp.n) sp.valid = false;
+  return RT_OK;
+}
+
+int rt_compute(rt_ctx* c, uint32_t frame_count) {
+  if (!c) return RT_ERR_INVALID;
+  if (c->lookahead_max <= 1 || c->detailed_counters || c->variant == 0 || c->accum_stale) return compute_frames(c, &frame_count, 1, 1);
+  // a frame traced ahead by an earlier call of this run?
+  if (c->spec.valid && c->spec.epoch == c->epoch && frame_count == c->spec.fc0 + c->spec.k &&
+      c->total_frames + 1 == c->spec.tf0 + c->spec.k && scene_ready(c)) {
+    const int r = consume_ahead(c, frame_count);
+    c->run_last_fc = frame_count;
+    c->run_last_tf = c->total_frames;
+    return r;
+  }
+  // does this call continue a run of consecutive frames?  Then trace ahead, twice as far as last time.
+  const bool continues = c->run_epoch == c->epoch && frame_count == c->run_last_fc + 1 && c->total_frames == c->run_last_tf;
+  c->look = continues ? std::min<uint32_t>(std::min<uint32_t>(c->look * 2u, c->lookahead_max), 64u) : 1u;
+  c->run_epoch = c->epoch;
+  uint32_t fcs[64];
+  for (uint32_t i = 0; i < c->look; i++) fcs[i] = frame_count + i;
+  const int r = compute_frames(c, fcs, c->look, 1);
+  c->run_last_fc = frame_count;
+  c->run_last_tf = c->total_frames;
+  return r;
+}
 
 int rt_compute_batch(rt_ctx* c, const uint32_t* frame_counts, uint32_t n) {
   if (!c) return RT_ERR_INVALID;
   if (n > 64) return fail(c, RT_ERR_INVALID, "at most 64 frames per batch");
-  return compute_frames(c, frame_counts, n);
+  c->epoch++;   // an explicit batch ends a run
+  return compute_frames(c, frame_counts, n, n);
+}
+
+int rt_set_lookahead(rt_ctx* c, uint32_t max_frames) {
+  if (!c) return RT_ERR_INVALID;
+  if (max_frames > 64) return fail(c, RT_ERR_INVALID, "at most 64 frames of lookahead");
+  c->lookahead_max = max_frames;
+  c->epoch++;
+  return RT_OK;
 }
 
 int rt_present(rt_ctx* c) {
@@ -1471,6 +1585,7 @@ int rt_read_accum(rt_ctx* c, float* out, size_t cap) {
 }
 int rt_write_accum(rt_ctx* c, const float* in, size_t bytes) {
   if (!c || !in) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   if (!c->accum.ptr || bytes != (size_t)c->width * c->height * 16)
     return fail(c, RT_ERR_INVALID, "accumulation size mismatch");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1483,9 +1598,16 @@ int rt_read_gbuffer(rt_ctx* c, uint8_t* albedo, float* normal_id, float* depth) 
   if (!c->render_target.ptr) return fail(c, RT_ERR_NOT_READY, "no G-buffer");
   const size_t n = (size_t)c->width * c->height;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (albedo) HIP_TRY(c, hipMemcpyAsync(albedo, c->render_target.ptr, n * 4, hipMemcpyDeviceToHost, c->stream));
-  if (normal_id) HIP_TRY(c, hipMemcpyAsync(normal_id, c->g_normal.ptr, n * 16, hipMemcpyDeviceToHost, c->stream));
-  if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->g_depth.ptr, n * 4, hipMemcpyDeviceToHost, c->stream));
+  const void *pa = c->render_target.ptr, *pn = c->g_normal.ptr, *pd = c->g_depth.ptr;
+  if (c->gbuf_slot >= 0 && (size_t)c->gbuf_slot < c->spec.slots.size()) {   // the frame of the last compute() was traced as part of a batch
+    const DevFrameSlot& sl = c->spec.slots[c->gbuf_slot];
+    pa = sl.albedo;
+    pn = sl.normal_id;
+    pd = sl.depth;
+  }
+  if (albedo) HIP_TRY(c, hipMemcpyAsync(albedo, pa, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (normal_id) HIP_TRY(c, hipMemcpyAsync(normal_id, pn, n * 16, hipMemcpyDeviceToHost, c->stream));
+  if (depth) HIP_TRY(c, hipMemcpyAsync(depth, pd, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RT_OK;
 }
@@ -1537,12 +1659,14 @@ int rt_reset_counters(rt_ctx* c) {
 }
 int rt_set_counting(rt_ctx* c, int detailed) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   c->detailed_counters = detailed != 0;
   return RT_OK;
 }
 int rt_set_stripes(rt_ctx* c, uint32_t stripe_rows, uint32_t rank, uint32_t count) {
   if (!c) return RT_ERR_INVALID;
   if (count > 1 && (stripe_rows == 0 || rank >= count)) return fail(c, RT_ERR_INVALID, "invalid stripe spec");
+  c->epoch++;
   c->stripe_rows = stripe_rows;
   c->stripe_rank = rank;
   c->stripe_count = count ? count : 1;
@@ -1567,6 +1691,7 @@ int rt_bind_present_source(rt_ctx* c, void* device_ptr) {
 }
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1575,15 +1700,18 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
 int rt_set_kernel_variant(rt_ctx* c, int variant) {
   if (!c || variant < 0 || variant > 3) return RT_ERR_INVALID;
   c->variant = variant;
+  c->epoch++;
   return RT_OK;
 }
 int rt_set_walk(rt_ctx* c, int walk) {
   if (!c || walk < 0 || walk > 2) return RT_ERR_INVALID;
   c->walk = walk;
+  c->epoch++;
   return RT_OK;
 }
 int rt_set_kernel_timing(rt_ctx* c, int enabled) {
   if (!c) return RT_ERR_INVALID;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   c->timing = enabled != 0;
   return RT_OK;
 }

@@ -173,7 +173,7 @@ def load_library(path=None):
         "rt_kernel_time_ms": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(u32)]),
         "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
-        "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]),
+        "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]), "rt_set_lookahead": (i32, [vp, u32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
@@ -191,7 +191,7 @@ EXPORTED_SYMBOLS = (
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_read_traversal_nodes rt_debug_read_pairs "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
-    "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk").split()
+    "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead").split()
 
 
 def _ptr(a):
@@ -408,6 +408,10 @@ class WebGPURenderer:
         1 = persistent waves + path regeneration, 0 = one pixel per lane megakernel; all bit-identical"""
         self._check(self.L.rt_set_kernel_variant(self.ctx, int(variant)), "setKernelVariant")
 
+    def setLookahead(self, max_frames):
+        """speculative lookahead of the live loop (rt_set_lookahead): consecutive compute(f) calls are traced ahead as batches"""
+        self._check(self.L.rt_set_lookahead(self.ctx, int(max_frames)), "setLookahead")
+
     def setWalk(self, walk):
         """traversal of the wavefront trace kernels: 1 = child-pair records (default), 0 = single nodes; bit-identical"""
         self._check(self.L.rt_set_walk(self.ctx, int(walk)), "setWalk")
@@ -484,8 +488,10 @@ class LiveLoop:
     t = totalFrameCount / update_interval / 60 (animation + rebuild), the scene is re-synced, accumulation restarts;
     every call traces one frame and presents."""
 
-    def __init__(self, renderer, bridge, width, height, update_interval=0):
+    def __init__(self, renderer, bridge, width, height, update_interval=0, lookahead=32):
         self.renderer, self.bridge = renderer, bridge
+        if lookahead > 1 and hasattr(renderer, "setLookahead"):
+            renderer.setLookahead(lookahead)    # a still scene accumulates frame after frame: trace them ahead in batches
         self.width, self.height = width, height
         self.update_interval = int(update_interval)      # <= 0: the world is never advanced (main.ts:127)
         self.frameCount = 0
