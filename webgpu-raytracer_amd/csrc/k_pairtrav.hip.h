@@ -113,7 +113,9 @@ typedef __attribute__((address_space(3))) void* rt_lvptr;
 // four ds_read_b128.  Measured (tools/gather_peak.hip, rows "4d"): a step costs the texture-address path what ONE 16-byte
 // load per lane cost (L1-resident 67-72 CU cycles at 40-64 lanes, L2-resident 92-97 / 149), and no register is shuffled
 // (the same fetch through registers, rows "4q", needs 44 selects + DPP moves per step: the first version of this walk was
-// VALU-bound on them).  The four regions (1 KB + 16 B of padding each, so that the read-back spreads over all banks) lie
+// VALU-bound on them; the same four loads as plain global_load_dwordx4 + four ds_write_b128 once they are back: 183.2
+// against 176.7 ms per 32-frame batch of the 263 k-triangle hall — an LDS-DMA load costs the wave ~175 cycles to issue, but
+// sixteen more live registers cost more).  The four regions (1 KB + 16 B of padding each, so that the read-back spreads over all banks) lie
 // over the wave's triangle work queue, which is only live inside pw_flush.
 #define RT_PW_REGION_SLOTS 65u   // 16-byte slots per region
 __device__ __forceinline__ void pw_fetch_dma(const f4* gpairs, f4* wave_lds, unsigned long long need_mask, uint32_t idx) {
