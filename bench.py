@@ -403,7 +403,8 @@ def main():
             trace_ms = kt["pathtrace"]["ms"] - kt["wf_shade"]["ms"] if kt["wf_trace_ext"]["launches"] else 0.0
             trace_bytes = 32.0 * kc["nodes_visited"] + 64.0 * kc["tris_tested"]    # per image (detailed pass = one image)
             per_image_trace_ms = trace_ms / m["steps"]
-            entry = {"config": name, "workload": "%s %dx%d, %d frames x depth %d, batches of %d" % (scene, cw, ch, nframes, depth, min(args.batch, nframes)),
+            n_inst = int(np.asarray(m["bridge"].instances).size // 36)
+            entry = {"config": name, "walk": "child-pair records (k_wf_trace_pairs)" if n_inst == 1 else "single nodes (k_wf_trace)", "workload": "%s %dx%d, %d frames x depth %d, batches of %d" % (scene, cw, ch, nframes, depth, min(args.batch, nframes)),
                      "ms_per_image": round(m["elapsed"] / m["steps"] * 1e3, 2),
                      "Mrays_s": round(m["rays"] / m["elapsed"] / 1e6, 1), "images": m["steps"],
                      "kernel_ms_per_image": {k: round(v["ms"] / m["steps"], 3) for k, v in kt.items() if v["launches"]},
@@ -420,7 +421,7 @@ def main():
                 # step, as a node step), 40 of 64 lanes active as in the trace kernels: every record from the L1 / from L2.
                 gp = gather_calibration()
                 steps_g = kc["nodes_visited"] / (per_image_trace_ms * 1e-3) / 1e9
-                roof_c = {"kernel": "k_wf_trace (any-hit + closest-hit launches)", "bound": "gather",
+                roof_c = {"kernel": "%s (any-hit + closest-hit launches)" % ("k_wf_trace_pairs" if n_inst == 1 else "k_wf_trace"), "bound": "gather",
                           "achieved": round(steps_g, 1), "peak": gp["l1_resident_Gps"] if gp else None,
                           "unit": "G node-steps/s",
                           "frac": round(steps_g / gp["l1_resident_Gps"], 4) if gp else None,

@@ -73,11 +73,12 @@ if [ "$WHAT" != calib ] && [ "$WHAT" != all ]; then
   exit 0
 fi
 mkdir -p $R/tools/bin
-for t in valu_peak gather_peak; do   # calibration binaries (git-ignored): build on the box when they did not travel
+for t in valu_peak gather_peak issue_peak; do   # calibration binaries (git-ignored): build on the box when they did not travel
   [ -x $R/tools/bin/$t ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/bin/$t $R/tools/$t.hip 2>/dev/null
 done
 timeout -k 10 120 $R/tools/bin/valu_peak > $OUT/${RTAG}_valu_peak.txt 2>&1
 timeout -k 10 300 $R/tools/bin/gather_peak > $OUT/${RTAG}_gather_peak.txt 2>&1
+timeout -k 10 120 $R/tools/bin/issue_peak > $OUT/${RTAG}_issue_peak.txt 2>&1
 timeout -k 10 200 python3 $R/tools/clock_check.py $OUT/${RTAG}_clock_check.json > $OUT/clock_check.log 2>&1
 python3 $R/tools/pmc_reference.py $OUT ${HEAD:-unknown} $OUT/pmc_reference.json > /dev/null
 ls $OUT

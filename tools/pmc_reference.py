@@ -75,7 +75,9 @@ for scene in ("sponza_like", "instanced1000", "glass_blob"):
     e = {"frames_per_image_profiled": PROFILED[scene][0], "frames_per_image": PROFILED[scene][1], "kernels": {}}
     hbm = 0.0
     for k, v in rows.items():
-        name = "any_hit" if "k_wf_trace<true" in k else "closest_hit"
+        name = "any_hit" if re.search(r"k_wf_trace(_pairs)?<true", k) else "closest_hit"
+        if "k_wf_trace_pairs" in k:
+            e["walk"] = "pairs"
         n = v.get("dispatches", 0)
         ke = {"dispatches": n}
         if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None:

@@ -85,15 +85,16 @@ struct DevFrameSlot {
 };
 
 // Wavefront form (large scenes): path state lives in HBM between the shade and trace stages.
-struct WfPath {       // one 64-B record (one half cache line) per (frame, pixel) item; after the first bounce the live
-  float4 c;           // paths are visited in queue order, i.e. scattered.  The ray itself is NOT here: the extension ray a
+struct WfPath {       // one 64-B record (one half cache line) per live path, in the order of the depth's active list.
+  float4 c;           // The ray itself is NOT here: the extension ray a
   float4 d;           // path continues along is in the ray queue at the path's slot (k_wf_shade reads it back from there).
   float4 e;           // c: throughput.xyz, bitcast(rng)   d: radiance.xyz, bitcast(flags): depth | specular << 8 |
   uint4 m;            // ended << 9 | nee_valid << 10   e: pending NEE term .xyz, prev_bsdf_pdf
 };                    // m: queue slot of the pending shadow ray, of the extension ray, 0, 0
 struct WfState {
-  WfPath* p;
-};
+  WfPath* p[2];       // [depth & 1]: the record of the path at position i of that depth's active list — the shade pass of depth
+};                    // d reads p[d & 1] in list order and writes p[(d + 1) & 1] at the slots it appends to the next list, so the
+                      // path state streams (round 2 kept one record per PATH ID: 64-byte gathers and scatters into 4 GB)
 struct WfQueues {
   uint32_t* active[2];    // path ids alive at the current / next depth
   uint32_t* shadow_ids;   // shadow-ray queue: path id ...

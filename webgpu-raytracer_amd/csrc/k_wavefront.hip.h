@@ -57,12 +57,12 @@ __device__ __forceinline__ void wq_finish(const WaveQueueWriter& w, uint32_t* id
   for (uint32_t i = w.pos + lane; i < w.end; i += 64u) ids[i] = RT_WF_INVALID;
 }
 
-__device__ __forceinline__ void wf_store_path(const WfState& W, uint32_t id, const PathState& p, uint32_t flags,
-                                              rt3 nee, uint32_t sslot, uint32_t eslot) {
-  W.p[id].c = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
-  W.p[id].d = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
-  W.p[id].e = make_float4(nee.x, nee.y, nee.z, p.prev_pdf);
-  W.p[id].m = make_uint4(sslot, eslot, 0u, 0u);   // the extension ray (p.ro, p.rd) is in Q.ext_rays[depth & 1] at eslot
+__device__ __forceinline__ void wf_store_path(WfPath* rec, const PathState& p, uint32_t flags, rt3 nee, uint32_t sslot,
+                                              uint32_t eslot) {
+  rec->c = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, rt_u2f(p.rng));
+  rec->d = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, rt_u2f(flags));
+  rec->e = make_float4(nee.x, nee.y, nee.z, p.prev_pdf);
+  rec->m = make_uint4(sslot, eslot, 0u, 0u);   // the extension ray (p.ro, p.rd) is in Q.ext_rays[depth & 1] at eslot
 }
 
 // One lane per path that is alive at `depth`.  FIRST: the paths start at the pixels of the batch (camera ray + G-buffer
@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
         setup_surface(S, p, true, g.x, g.y, slot.albedo[p.pixel]);
       }
     } else {
-      const float4 d = W.p[id].d, e = W.p[id].e;
-      const uint4 m = W.p[id].m;     // m.x: slot of the shadow ray, m.y: slot of the extension ray
+      const WfPath* const rec = W.p[depth & 1u] + idx;   // the path's record sits at its position in this depth's list
+      const float4 d = rec->d, e = rec->e;
+      const uint4 m = rec->m;     // m.x: slot of the shadow ray, m.y: slot of the extension ray
       const uint32_t fl = rt_f2u(d.w);
       p.radiance = xyz(d);
       if (m.x != RT_WF_INVALID && (fl & WF_FLAG_NEE_VALID) != 0u && Q.occluded[m.x] == 0u)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
         live = false;
       } else {
         const float4* went = Q.ext_rays[(depth + 1u) & 1u];   // the previous depth's extension rays: the ray the path went along
-        const float4 a = went[2 * m.y], b = went[2 * m.y + 1], c = W.p[id].c;
+        const float4 a = went[2 * m.y], b = went[2 * m.y + 1], c = rec->c;
         p.ro = xyz(a);
         p.rd = xyz(b);
         p.prev_pdf = e.w;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_wf_shade(DevScene S, De
       } else {
         const uint32_t flags = (p.depth & 0xffu) | (p.specular ? WF_FLAG_SPECULAR : 0u) |
                                (bo.ended ? WF_FLAG_ENDED : 0u) | (bo.nee_valid ? WF_FLAG_NEE_VALID : 0u);
-        wf_store_path(W, id, p, flags, bo.nee, sslot, eslot);
+        wf_store_path(W.p[(depth + 1u) & 1u] + nslot, p, flags, bo.nee, sslot, eslot);   // stored iff the path is on the next list
       }
     }
   }

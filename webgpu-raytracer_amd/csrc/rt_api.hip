@@ -1098,8 +1098,7 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   const size_t npx = (size_t)c->width * c->height;
   const size_t items = npx * n;
   if (items >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "batch too large for the wavefront queues");
-  int r = ensure_buffer(c, c->wf_state, items * sizeof(WfPath), false);
-  if (r < 0) return r;
+  int r;
   // queues are reserved in chunks of RT_WF_CHUNK per wave: room for every item plus one partial chunk per wave
   // shade kernels: persistent waves that loop over the items; every wave may leave one partly used chunk per queue
   const uint32_t shade_blocks = (uint32_t)std::min<size_t>((items + 255) / 256, (size_t)c->num_cus * (size_t)c->shade_per_cu);
@@ -1108,12 +1107,15 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
   // depths (3 x 32 B) + hits (16 B)
   r = ensure_buffer(c, c->wf_queues, qcap * 132, false);
   if (r < 0) return r;
+  r = ensure_buffer(c, c->wf_state, 2 * qcap * sizeof(WfPath), false);   // path records in list order, double-buffered by depth parity
+  if (r < 0) return r;
   const uint32_t depths = c->max_depth ? c->max_depth : 1u;
   r = ensure_buffer(c, c->wf_counters, (size_t)(depths + 2) * 32, false);
   if (r < 0) return r;
   HIP_TRY(c, hipMemsetAsync(c->wf_counters.ptr, 0, (size_t)(depths + 2) * 32, c->stream));
   WfState W;
-  W.p = (WfPath*)c->wf_state.ptr;
+  W.p[0] = (WfPath*)c->wf_state.ptr;
+  W.p[1] = W.p[0] + qcap;
   WfQueues Q;
   char* qb = (char*)c->wf_queues.ptr;
   Q.shadow_rays = (float4*)qb;
