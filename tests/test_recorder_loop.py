@@ -90,6 +90,8 @@ def test_live_loop_follows_main_ts(W):
     loop = W.LiveLoop(rec, b, 64, 48, update_interval=3)
     for _ in range(8):
         loop.render_frame()
+    assert rec.calls[0][0] == "setLookahead"      # the loop lets the library trace a still scene's consecutive frames ahead
+    rec.calls = rec.calls[1:]
     names = [c[0] for c in rec.calls]
     first_sync = ["updateCombinedBVH", "updateBuffer", "updateBuffer", "updateCombinedGeometry", "updateBuffer", "updateBuffer",
                   "updateSceneUniforms", "resetAccumulation"]
@@ -104,6 +106,7 @@ def test_live_loop_follows_main_ts(W):
     loop2 = W.LiveLoop(rec2, b2, 64, 48, update_interval=0)
     for _ in range(4):
         loop2.render_frame()
+    rec2.calls = [c for c in rec2.calls if c[0] != "setLookahead"]
     assert b2.updates == [] and [c[1] for c in rec2.calls if c[0] == "compute"] == [1, 2, 3, 4]
 
 
