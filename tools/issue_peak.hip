@@ -22,10 +22,11 @@
     }                                                                             \
   } while (0)
 
-#define V8 "v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
-#define S8 "s_add_u32 %9, %9, 1\n s_add_u32 %10, %10, 1\n s_add_u32 %11, %11, 1\n s_add_u32 %12, %12, 1\n s_add_u32 %13, %13, 1\n s_add_u32 %14, %14, 1\n s_add_u32 %15, %15, 1\n s_add_u32 %16, %16, 1\n"
-#define VS8 "v_add_f32 %0, %0, %8\n s_add_u32 %9, %9, 1\n v_add_f32 %1, %1, %8\n s_add_u32 %10, %10, 1\n v_add_f32 %2, %2, %8\n s_add_u32 %11, %11, 1\n v_add_f32 %3, %3, %8\n s_add_u32 %12, %12, 1\n" \
-            "v_add_f32 %4, %4, %8\n s_add_u32 %13, %13, 1\n v_add_f32 %5, %5, %8\n s_add_u32 %14, %14, 1\n v_add_f32 %6, %6, %8\n s_add_u32 %15, %15, 1\n v_add_f32 %7, %7, %8\n s_add_u32 %16, %16, 1\n"
+// operands: %0-%7 = eight VGPR accumulators, %8-%15 = eight SGPR counters (all read-write), %16 = the VGPR increment
+#define V8 "v_add_f32 %0, %0, %16\n v_add_f32 %1, %1, %16\n v_add_f32 %2, %2, %16\n v_add_f32 %3, %3, %16\n v_add_f32 %4, %4, %16\n v_add_f32 %5, %5, %16\n v_add_f32 %6, %6, %16\n v_add_f32 %7, %7, %16\n"
+#define S8 "s_add_u32 %8, %8, 1\n s_add_u32 %9, %9, 1\n s_add_u32 %10, %10, 1\n s_add_u32 %11, %11, 1\n s_add_u32 %12, %12, 1\n s_add_u32 %13, %13, 1\n s_add_u32 %14, %14, 1\n s_add_u32 %15, %15, 1\n"
+#define VS8 "v_add_f32 %0, %0, %16\n s_add_u32 %8, %8, 1\n v_add_f32 %1, %1, %16\n s_add_u32 %9, %9, 1\n v_add_f32 %2, %2, %16\n s_add_u32 %10, %10, 1\n v_add_f32 %3, %3, %16\n s_add_u32 %11, %11, 1\n" \
+            "v_add_f32 %4, %4, %16\n s_add_u32 %12, %12, 1\n v_add_f32 %5, %5, %16\n s_add_u32 %13, %13, 1\n v_add_f32 %6, %6, %16\n s_add_u32 %14, %14, 1\n v_add_f32 %7, %7, %16\n s_add_u32 %15, %15, 1\n"
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_issue(int iters, float* out, unsigned long long* stamps) {
@@ -33,22 +34,23 @@ __global__ __launch_bounds__(256) void k_issue(int iters, float* out, unsigned l
   unsigned s[8];
   for (int i = 0; i < 8; i++) {
     a[i] = (float)(threadIdx.x + i);
-    s[i] = blockIdx.x + i;
+    s[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x + i));   // uniform: lives in an SGPR
   }
   const float inc = 1.0f;
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; it++) {
 #define OPERANDS                                                                                                     \
-  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])                   \
-  : "v"(inc), "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7])                 \
+  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),                  \
+    "+s"(s[0]), "+s"(s[1]), "+s"(s[2]), "+s"(s[3]), "+s"(s[4]), "+s"(s[5]), "+s"(s[6]), "+s"(s[7])                   \
+  : "v"(inc)                                                                                                         \
   : "scc"
     if (KIND == 0) asm volatile(V8 V8 V8 V8 OPERANDS);                       // 32 VALU
-    if (KIND == 1) asm volatile(S8 S8 S8 S8 OPERANDS);                       // 32 SALU (results discarded: timing only)
+    if (KIND == 1) asm volatile(S8 S8 S8 S8 OPERANDS);                       // 32 SALU
     if (KIND == 2) asm volatile(VS8 VS8 OPERANDS);                           // 16 VALU + 16 SALU, alternating
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float acc = 0.0f;
-  for (int i = 0; i < 8; i++) acc += a[i];
+  for (int i = 0; i < 8; i++) acc += a[i] + (float)s[i];
   out[blockIdx.x * 256 + threadIdx.x] = acc;
   if (threadIdx.x == 0) {
     stamps[2 * blockIdx.x] = c1 - c0;
