@@ -89,10 +89,17 @@ def gather_calibration():
                         out["l1_resident_Gps"] = float(f[4])
                     elif f[0] == "4MB":
                         out["l2_resident_Gps"] = float(f[4])
+                # the child-pair walk: one 64-byte record (TWO node tests) per step, quad-cooperative LDS-DMA fetch (rows "4d")
+                if len(f) >= 6 and f[1:4] == ["4d", "64", "6"]:
+                    if f[0] == "16KB":
+                        out["pairs_l1_resident_Gnodes"] = 2.0 * float(f[4])
+                    elif f[0] == "4MB":
+                        out["pairs_l2_resident_Gnodes"] = 2.0 * float(f[4])
         except OSError:
             continue
-        if len(out) == 2:
-            out["source"] = "profiles/%s (tools/gather_peak.hip: 32-B records, 64 of 64 lanes, 16 KB / 4 MB table)" % name
+        if "l1_resident_Gps" in out and "l2_resident_Gps" in out:
+            out["source"] = ("profiles/%s (tools/gather_peak.hip: 64 of 64 lanes, 16 KB / 4 MB table; 32-B records with 2 loads per "
+                             "lane, and 64-B records fetched quad-cooperatively by LDS-DMA = two node tests per step)" % name)
             return out
     return None
 
@@ -154,6 +161,23 @@ def rehearsal(args, rank, world):
               flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def issue_calibration():
+    """profiles/r03_issue_peak.txt (tools/issue_peak.hip): wave-instructions per cycle per SIMD of independent VALU, SALU and
+    1 : 1 interleaved streams at W waves per SIMD."""
+    path = os.path.join(REPO, "profiles", "r03_issue_peak.txt")
+    out = {}
+    try:
+        for line in open(path):
+            m = line.split()
+            if len(m) >= 4 and m[0] in ("v_add_f32", "s_add_u32"):
+                kind = "mixed" if (len(m) >= 6 and m[1] == ":") else ("valu" if m[0] == "v_add_f32" else "salu")
+                waves, rate = (int(m[3]), float(m[4])) if kind == "mixed" else (int(m[1]), float(m[2]))
+                out.setdefault(kind, {})[waves] = rate
+    except OSError:
+        return None
+    return out or None
 
 
 def pmc_reference():
@@ -365,6 +389,18 @@ def main():
                     roof[k] = {"value": pt[k], "source": src}
             if pt.get("measured_issue_peak_Tlane"):
                 roof["frac_of_measured_issue_peak"] = round(roof["achieved"] / pt["measured_issue_peak_Tlane"], 4)
+            ic = issue_calibration()
+            if ic and pt.get("insts_valu_per_launch") and pt.get("insts_salu_per_launch") and pt.get("effective_clock_GHz"):
+                # the kernel's whole instruction stream (vector + scalar + LDS) against what a SIMD issues of a 1 : 1 vector /
+                # scalar stream at this kernel's 4 waves per SIMD: the bound the walks actually run into
+                insts = (pt["insts_valu_per_launch"] + pt["insts_salu_per_launch"] + pt.get("insts_lds_per_launch", 0.0)) * scale
+                simd_cycles = launch_ms * 1e-3 * pt["effective_clock_GHz"] * 1e9 * 256 * 4
+                rate = insts / simd_cycles
+                roof["issue"] = {"wave_instr_per_cycle_per_simd": round(rate, 4), "waves_per_simd": 4,
+                                 "measured_mixed_issue_rate": ic.get("mixed", {}).get(4), "measured_valu_only": ic.get("valu", {}).get(4),
+                                 "measured_salu_only": ic.get("salu", {}).get(4),
+                                 "frac_of_measured_mixed_issue_rate": round(rate / ic["mixed"][4], 4) if ic.get("mixed", {}).get(4) else None,
+                                 "source": "instruction counts: " + str(src) + "; issue rates: profiles/r03_issue_peak.txt (tools/issue_peak.hip)"}
             if pt.get("hbm_bytes_per_launch"):
                 tb = pt["hbm_bytes_per_launch"] * scale
                 roof["traffic"] = tb
@@ -420,6 +456,8 @@ def main():
                 # takes DEPENDENT lane-divergent 16-byte gathers — tools/gather_peak.hip, 32-byte records (2 x dwordx4 per
                 # step, as a node step), 40 of 64 lanes active as in the trace kernels: every record from the L1 / from L2.
                 gp = gather_calibration()
+                if gp and n_inst == 1 and "pairs_l1_resident_Gnodes" in gp:   # priced against the fetch this walk uses
+                    gp = dict(gp, l1_resident_Gps=gp["pairs_l1_resident_Gnodes"], l2_resident_Gps=gp["pairs_l2_resident_Gnodes"])
                 steps_g = kc["nodes_visited"] / (per_image_trace_ms * 1e-3) / 1e9
                 roof_c = {"kernel": "%s (any-hit + closest-hit launches)" % ("k_wf_trace_pairs" if n_inst == 1 else "k_wf_trace"), "bound": "gather",
                           "achieved": round(steps_g, 1), "peak": gp["l1_resident_Gps"] if gp else None,
