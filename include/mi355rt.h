@@ -20,6 +20,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "mi355rt_layout.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -209,6 +211,28 @@ int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
  * the original-index -> new-index table, and the per-instance BLAS roots (any pointer may be NULL).  Returns the node count. */
 int rt_debug_read_traversal_nodes(rt_ctx* ctx, float* tnodes_out, uint32_t* new_index_out, uint32_t* inst_root_out,
                                   uint32_t cap_nodes);
+/* Device-resident World::update(t): derive EVERY bridge array of this frame on the GPU, inside the
+ * renderer's own scene buffers, from the static scene description and the frame's joint matrices (rt_world_frame,
+ * mi355rt_layout.h): linear-blend skinning (rebuilder.rs:36-91), the binned-SAH BLAS of every geometry (bvh/blas.rs,
+ * without host synchronisation between tree levels), topology / light / draw-command packing (rebuilder.rs:121-168,
+ * lib.rs:237-270), the median-split TLAS (bvh/tlas.rs:58-111) and the packed instances - byte for byte the arrays
+ * World::update would have produced, which therefore need no upload: it replaces update(t) + updateCombinedGeometry +
+ * updateBuffer(topology / instance / lights / draw commands) + updateCombinedBVH of the live loop (src/main.ts:133-163).
+ * The signature (with the rt_ctx* as `user`) is ms_device_updater's of mi355scene.h.  The static description is copied
+ * to the device when frame->static_epoch differs from the last call's; the pointers need only live during the call.
+ * One stream synchronisation at the end (node counts, the TLAS root).  Returns RT_OK / RT_REALLOCATED, or < 0: a
+ * description this path does not take (an instance of an empty geometry, a NaN instance box; the caller then runs the
+ * host update and uploads as before) or an error. */
+int rt_world_update(rt_ctx* ctx, const rt_world_frame* frame);
+/* Stream time (ms, HIP events) of the last rt_world_update: kernels and the small copies, without host work. */
+double rt_world_last_ms(const rt_ctx* ctx);
+/* Read a bridge array back from the device-resident world (tests; a host that wants the arrays after all).  out == NULL:
+ * only *bytes_out is set. */
+typedef enum rt_world_array {
+  RT_WORLD_VERTICES = 0, RT_WORLD_NORMALS, RT_WORLD_UVS, RT_WORLD_TOPOLOGY, RT_WORLD_TLAS, RT_WORLD_BLAS, RT_WORLD_INSTANCES,
+  RT_WORLD_LIGHTS, RT_WORLD_DRAW_COMMANDS
+} rt_world_array;
+int rt_world_read(rt_ctx* ctx, int which, void* out, size_t cap_bytes, size_t* bytes_out);
 /* Debug / test read-back of the child-pair records the trace kernels walk (csrc/k_pairs.hip.h): pairs_out receives
  * 16 floats per inner node, root_rec_out 8 floats per instance plus 8 for the TLAS root (either may be NULL).  Returns the
  * number of pair records, or < 0 (cap_pairs too small, no scene). */

@@ -75,6 +75,39 @@ typedef struct rt_scene_uniforms {
   uint32_t tail_pad[4];    /* buffer is 256 bytes (ResourceManager.ts:65) */
 } rt_scene_uniforms;
 
+
+/* ---- device-resident World::update(t): what the scene compiler hands the renderer so that the
+ * per-frame half of World::update (lib.rs:149-270) runs on the GPU and the bridge arrays never leave HBM.
+ *
+ * STATIC part (changes only when `static_epoch` does: scene load / animation file load): per geometry the skinning
+ * input of rebuilder.rs:36-91 (base positions / normals / uvs, joints, weights), its index list and its per-triangle
+ * attribute rows (geometry.rs:6-25), and the instance list of lib.rs:194-230 in DECLARATION order with the transforms
+ * the update would leave in place.  PER-FRAME part: the joint matrices global(joint) * inverse_bind of every skin
+ * (rebuilder.rs:40-47) after the animation was sampled at t and the scene graph re-evaluated (lib.rs:149-184) - a few
+ * hundred bytes.  Everything else of update(t) - skinning, BLAS build (bvh/blas.rs), topology / light / draw-command
+ * packing (rebuilder.rs:121-168, lib.rs:237-270), TLAS (bvh/tlas.rs:58-111), instance packing - is derived from these
+ * on the device by rt_world_update (include/mi355rt.h). */
+typedef struct rt_world_geometry {
+  const float* positions;     /* 3 f32 per vertex (base pose) */
+  const float* normals;       /* 3 f32 per vertex */
+  const float* uvs;           /* 2 f32 per vertex, n_uvs of them (vertices beyond get 0, 0) */
+  const uint32_t* joints;     /* 4 per vertex */
+  const float* weights;       /* 4 per vertex */
+  const uint32_t* indices;    /* 3 per triangle, geometry-local vertex ids */
+  const float* attributes;    /* 16 f32 per triangle (the 64 bytes after rt_topology.pad) */
+  uint32_t n_verts, n_uvs, n_tris;
+  int32_t skin;               /* index into the frame's skins, -1 = not skinned */
+} rt_world_geometry;
+
+typedef struct rt_world_frame {
+  uint64_t static_epoch;               /* the static part below is unchanged while this is */
+  uint32_t n_geometries, n_instances, n_skins, pad;
+  const rt_world_geometry* geometries; /* n_geometries */
+  const rt_instance* instances;        /* n_instances, declaration order; blas_node_offset is filled in on the device */
+  const uint32_t* skin_first;          /* n_skins + 1: first joint matrix of each skin in joint_mats */
+  const float* joint_mats;             /* 16 f32 each (column-major), this frame */
+} rt_world_frame;
+
 #ifdef __cplusplus
 }
 static_assert(sizeof(rt_topology) == 80, "MeshTopology is 80 bytes");

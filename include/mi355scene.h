@@ -23,6 +23,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "mi355rt_layout.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -65,6 +67,17 @@ size_t ms_world_node_count(const ms_world* w);
 typedef int (*ms_blas_builder)(void* user, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
                                float* nodes_out, uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
 void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user);
+/* Move the whole per-frame half of World::update(t) to the device: with an updater set,
+ * ms_world_update(t) samples the animation, re-evaluates the scene graph and computes the joint matrices (lib.rs:149-184,
+ * rebuilder.rs:40-47) and hands them - with the static scene description, see rt_world_frame in mi355rt_layout.h - to
+ * `fn`; libmi355rt.so's rt_world_update has this signature with its rt_ctx* as `user`.  The updater derives every
+ * bridge array on the GPU, inside the renderer's own buffers: the host arrays behind the getters below are then NOT
+ * refreshed (ms_world_device_resident() = 1; they keep the sizes and contents of the last host update) and nothing
+ * needs re-uploading.  When the updater fails (< 0) this update runs on the host like without one
+ * (ms_world_device_resident() = 0, ms_last_error() says why).  fn == NULL removes the updater. */
+typedef int (*ms_device_updater)(void* user, const rt_world_frame* frame);
+void ms_world_set_device_updater(ms_world* w, ms_device_updater fn, void* user);
+int ms_world_device_resident(const ms_world* w);
 /* The CPU builder itself, with the hook's signature minus `user`: BVHBuilder::new + build_with_ids of bvh/blas.rs:20-85
  * on one mesh (4 f32 per vertex, 3 u32 per triangle) -> 8 f32 per node {min.xyz, bits(skip)} {max.xyz, bits(data)} and
  * the triangle order.  0 on success, -1 on a bad argument.  tests/test_bvh_independent.py pins it with node arrays

@@ -24,6 +24,7 @@
 #include "../../include/mi355rt.h"
 #include "kernels.hip.h"
 #include "bvh_build.hip.h"
+#include "world_update.hip.h"
 
 namespace {
 
@@ -59,9 +60,25 @@ struct rt_ctx {
 
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
-  uint32_t bv_levels = 0;
-  void* bv_pinned = nullptr;  // 64 KB of pinned host memory for the per-level read-backs of rt_build_blas
-  DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_active, bv_out, bv_counters, bv_big;  // rt_build_blas work space
+  uint32_t bv_levels = 0, bv_big_levels = 0, bv_last_tris = 0;   // depth of the last rt_build_blas tree: how many levels the next build launches
+  void* bv_pinned = nullptr;  // 64 KB of pinned host memory for the read-back of the build's bookkeeping
+  DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_out, bv_counters, bv_big;  // BLAS build work space
+  // device-resident World::update(t) (rt_world_update, csrc/world_update.hip.h)
+  struct {
+    bool valid = false;
+    uint64_t epoch = 0;                   // rt_world_frame::static_epoch the static buffers were made from
+    std::vector<wu::Geom> geoms;          // device pointers into `stat`
+    std::vector<uint32_t> levels, big_levels;   // per geometry: tree levels / large-node levels the next build launches
+    std::vector<float> inst_scale2;       // per instance (declaration order): squared linear scale (treelet weights)
+    std::vector<uint32_t> inst_geom;
+    uint32_t n_joints = 0, n_verts = 0, n_tris = 0, n_lights = 0, n_tlas = 0, n_inst = 0;
+    DeviceBuffer stat, joints, raw_inst, geom_rows, node_base, em_flag, em_list, em_blk, tlas_scratch, stats;
+    void* pinned = nullptr;               // joint-matrix staging and the end-of-update read-back
+    size_t pinned_bytes = 0;
+    wu::TlasArgs tlas;
+    double last_ms = 0;                   // stream time of the last update (rt_world_last_ms)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  } world;
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, tri_shade, inst_trav, light_rec;
   DeviceBuffer tnodes, node_key, node_newidx, inst_root, root_w, treelet_work;   // k_treelet.hip.h
@@ -556,10 +573,15 @@ void rt_destroy(rt_ctx* c) {
                          &c->nodes, &c->textures, &c->tri_geom, &c->tri_shade, &c->inst_trav, &c->light_rec, &c->accum, &c->render_target,
                          &c->g_normal, &c->g_depth, &c->history[0], &c->history[1], &c->counters, &c->ticket,
                          &c->slots, &c->gbuf_batch, &c->frame_col, &c->wf_state, &c->wf_queues, &c->wf_counters,
-                         &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_active, &c->bv_out,
+                         &c->tex_staging, &c->bv_in, &c->bv_tri, &c->bv_order, &c->bv_nodes, &c->bv_out,
                          &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
-                         &c->inst_root, &c->root_w, &c->treelet_work, &c->pairs, &c->pair_of, &c->pair_parent, &c->root_rec};
+                         &c->inst_root, &c->root_w, &c->treelet_work, &c->pairs, &c->pair_of, &c->pair_parent, &c->root_rec,
+                         &c->world.stat, &c->world.joints, &c->world.raw_inst, &c->world.geom_rows, &c->world.node_base,
+                         &c->world.em_flag, &c->world.em_list, &c->world.em_blk, &c->world.tlas_scratch, &c->world.stats};
   for (DeviceBuffer* b : all) free_buffer(*b);
+  if (c->world.pinned) (void)hipHostFree(c->world.pinned);
+  if (c->world.ev0) (void)hipEventDestroy(c->world.ev0);
+  if (c->world.ev1) (void)hipEventDestroy(c->world.ev1);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -702,8 +724,104 @@ int rt_read_texture_layer(rt_ctx* c, uint32_t layer, uint8_t* out, size_t cap) {
   return RT_OK;
 }
 
-// Binned-SAH BLAS build on the GPU (csrc/bvh_build.hip.h): the tree and the triangle order of the scene compiler's
-// BlasBuilder, byte for byte.  Host arrays in, host arrays out (the scene compiler consumes them).
+// ---- binned-SAH BLAS build on the GPU (csrc/bvh_build.hip.h) ----
+// Work space of one build of n triangles (shared by successive builds: they run one after the other on c->stream).
+static int blas_workspace(rt_ctx* c, uint32_t n_tris, bvhb::Build& B, bvhb::BigNode*& d_big, bvhb::Chunk*& d_chunks, uint32_t*& d_cnt,
+                          uint32_t*& d_base, uint32_t*& d_lb, uint32_t*& d_blk) {
+  const size_t n = n_tris, max_nodes = 2 * n;  // a binary tree with >= 1 triangle per leaf has < 2n nodes
+  const size_t n_blk = (n + 1023) / 1024 + 1;
+  int r;
+  if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
+  // ord[0], ord[1], order_final, scratch_l, scratch_r, leaf_flag, small_ids, lb (n + 1), block counts; bin cache (bytes)
+  if ((r = ensure_buffer(c, c->bv_order, (8 * n + 4 + n_blk) * 4 + n + 16, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_counters, sizeof(bvhb::Ctl), false)) < 0) return r;
+  const uint32_t nb = bvhb::big_cap(n_tris), nc = bvhb::chunk_cap(n_tris);
+  if ((r = ensure_buffer(c, c->bv_big, (size_t)nb * sizeof(bvhb::BigNode) + (size_t)nc * (sizeof(bvhb::Chunk) + 16), false)) < 0) return r;
+  float4* tri = (float4*)c->bv_tri.ptr;
+  uint32_t* ord = (uint32_t*)c->bv_order.ptr;
+  B.tri_mn = tri;
+  B.tri_mx = tri + n;
+  B.tri_c = tri + 2 * n;
+  B.ord[0] = ord;
+  B.ord[1] = ord + n;
+  B.order_final = ord + 2 * n;
+  B.scratch_l = ord + 3 * n;
+  B.scratch_r = ord + 4 * n;
+  B.leaf_flag = ord + 5 * n;
+  B.small_ids = ord + 6 * n;
+  d_lb = ord + 7 * n;              // n + 1 entries
+  d_blk = ord + 8 * n + 4;
+  B.bin_cache = (uint8_t*)(d_blk + n_blk);
+  B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
+  B.ctl = (bvhb::Ctl*)c->bv_counters.ptr;
+  d_big = (bvhb::BigNode*)c->bv_big.ptr;
+  d_chunks = (bvhb::Chunk*)(d_big + nb);
+  d_cnt = (uint32_t*)(d_chunks + nc);
+  d_base = d_cnt + 2 * (size_t)nc;
+  return RT_OK;
+}
+static uint32_t ceil_log2(uint32_t v) {
+  uint32_t l = 0;
+  while (l < 32u && (1ull << l) < v) l++;
+  return l;
+}
+// first guesses for a mesh never built before: tree depth and the levels that still hold a node above kBig triangles
+static uint32_t blas_guess_levels(uint32_t n_tris) { return std::min<uint32_t>(bvhb::kMaxLevels, ceil_log2(std::max(n_tris / 4u, 1u)) + 8u); }
+static uint32_t blas_guess_big_levels(uint32_t n_tris) { return n_tris > bvhb::kBig ? ceil_log2((n_tris + bvhb::kBig - 1) / bvhb::kBig) + 3u : 0u; }
+
+// Enqueue one whole build on c->stream: `levels` tree levels (the first `big_levels` with the large-node kernels), the
+// leaf prefix sum and the node array, written to out + 2 * node_base[0] (node_base, device: [1] = [0] + node count is
+// written; NULL: at out).  Nothing is read back: the caller checks Ctl::cnt[levels] == 0 (the tree was not deeper)
+// whenever it next synchronises.  d_pos / d_idx / out are device pointers.
+static int blas_enqueue(rt_ctx* c, const float4* d_pos, const uint32_t* d_idx, uint32_t n_tris, uint32_t levels, uint32_t big_levels,
+                        float4* out, uint32_t* node_base, uint32_t topo_start, bvhb::Build& B) {
+  bvhb::BigNode* d_big;
+  bvhb::Chunk* d_chunks;
+  uint32_t *d_cnt, *d_base, *d_lb, *d_blk;
+  int r = blas_workspace(c, n_tris, B, d_big, d_chunks, d_cnt, d_base, d_lb, d_blk);
+  if (r < 0) return r;
+  levels = std::min<uint32_t>(levels, bvhb::kMaxLevels);
+  big_levels = std::min(big_levels, levels);
+  hipLaunchKernelGGL(bvhb::k_tri_boxes, dim3((n_tris + 255) / 256), dim3(256), 0, c->stream, d_pos, d_idx, n_tris, B);
+  const dim3 gn_thread((bvhb::big_cap(n_tris) + 63) / 64), gn_wave(bvhb::big_cap(n_tris)), gc(bvhb::chunk_cap(n_tris));
+  for (uint32_t level = 0; level < levels; level++) {
+    const uint32_t bound = level >= 31u ? n_tris : std::min<uint32_t>(1u << level, n_tris);   // most nodes the level can have
+    if (level < big_levels) {
+      hipLaunchKernelGGL(bvhb::k_big_plan, dim3(1), dim3(1024), 0, c->stream, B, level, d_big, d_chunks);
+      if (level == 0)  // only the root reduces its box; children get theirs from the parent's sweep
+        hipLaunchKernelGGL(bvhb::k_big_bounds, gc, dim3(256), 0, c->stream, B, level, d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_setup, gn_thread, dim3(64), 0, c->stream, B, d_big);
+      hipLaunchKernelGGL(bvhb::k_big_bin, gc, dim3(256), 0, c->stream, B, level, d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_split, gn_wave, dim3(64), 0, c->stream, B, d_big);
+      hipLaunchKernelGGL(bvhb::k_big_count, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks, d_cnt);
+      hipLaunchKernelGGL(bvhb::k_big_scan, gn_thread, dim3(64), 0, c->stream, B, d_big, (const uint32_t*)d_cnt, d_base);
+      hipLaunchKernelGGL(bvhb::k_big_scatter, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks,
+                         (const uint32_t*)d_cnt, (const uint32_t*)d_base);
+      hipLaunchKernelGGL(bvhb::k_big_swap, gc, dim3(256), 0, c->stream, B, level, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL(bvhb::k_big_copy, gc, dim3(256), 0, c->stream, B, level, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
+      hipLaunchKernelGGL((bvhb::k_level<256, true>), dim3(std::min<uint32_t>(bound, 1024u)), dim3(256), 0, c->stream, B, level);
+    } else if (level < big_levels + 3u) {
+      hipLaunchKernelGGL((bvhb::k_level<256, false>), dim3(std::min<uint32_t>(bound, 2048u)), dim3(256), 0, c->stream, B, level);
+    } else {
+      // deep levels: tens of thousands of nodes of a few dozen triangles — one wave per node keeps four times as many
+      // nodes in flight per CU
+      hipLaunchKernelGGL((bvhb::k_level<64, false>), dim3(std::min<uint32_t>(bound, 8192u)), dim3(64), 0, c->stream, B, level);
+    }
+  }
+  const uint32_t n_blk = (n_tris + 1023u) / 1024u;
+  hipLaunchKernelGGL(bvhb::k_scan_blocks, dim3(n_blk), dim3(1024), 0, c->stream, (const uint32_t*)B.leaf_flag, n_tris, d_blk);
+  hipLaunchKernelGGL(bvhb::k_scan_top, dim3(1), dim3(1024), 0, c->stream, d_blk, n_blk, B.ctl, node_base);
+  hipLaunchKernelGGL(bvhb::k_scan_apply, dim3(n_blk), dim3(1024), 0, c->stream, (const uint32_t*)B.leaf_flag, n_tris, (const uint32_t*)d_blk,
+                     (const bvhb::Ctl*)B.ctl, d_lb);
+  hipLaunchKernelGGL(bvhb::k_emit, dim3((2 * n_tris + 255) / 256), dim3(256), 0, c->stream, (const bvhb::BNode*)B.nodes, (const bvhb::Ctl*)B.ctl,
+                     (const uint32_t*)d_lb, (const uint32_t*)node_base, topo_start, out);
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+// The tree and the triangle order of the scene compiler's BlasBuilder, byte for byte.  Host arrays in, host arrays out
+// (the scene compiler's ms_blas_builder hook; the device-resident update, rt_world_update, uses blas_enqueue directly).
 int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
                   uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out) {
   if (!c || !n_nodes_out) return RT_ERR_INVALID;
@@ -714,145 +832,398 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
   for (size_t i = 0; i < (size_t)n_tris * 3; i++)
     if (indices[i] >= n_verts) return fail(c, RT_ERR_INVALID, "rt_build_blas: vertex index out of range");
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t n = n_tris, max_nodes = 2 * n;  // a binary tree with >= 1 triangle per leaf has < 2n nodes
+  const size_t n = n_tris;
   int r;
   if ((r = ensure_buffer(c, c->bv_in, (size_t)n_verts * 16 + n * 12, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_order, n * 21 + 16, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_active, n * 4, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_out, max_nodes * 32, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_counters, 16, false)) < 0) return r;
+  if ((r = ensure_buffer(c, c->bv_out, 2 * n * 32, false)) < 0) return r;
   float4* d_pos = (float4*)c->bv_in.ptr;
   uint32_t* d_idx = (uint32_t*)((char*)c->bv_in.ptr + (size_t)n_verts * 16);
   HIP_TRY(c, hipMemcpyAsync(d_pos, verts4, (size_t)n_verts * 16, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(d_idx, indices, n * 12, hipMemcpyHostToDevice, c->stream));
-  float4* tri = (float4*)c->bv_tri.ptr;
-  uint32_t* ord = (uint32_t*)c->bv_order.ptr;
-  bvhb::Build B;
-  B.tri_mn = tri;
-  B.tri_mx = tri + n;
-  B.tri_c = tri + 2 * n;
-  B.order_in = ord;
-  B.order_out = ord + n;
-  B.order_final = ord + 2 * n;
-  B.scratch_l = ord + 3 * n;
-  B.scratch_r = ord + 4 * n;
-  B.bin_cache = (uint8_t*)(ord + 5 * n);
-  B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
-  B.counters = (uint32_t*)c->bv_counters.ptr;
-  uint32_t* d_ids = (uint32_t*)c->bv_active.ptr;
-  hipLaunchKernelGGL(bvhb::k_tri_boxes, dim3((n_tris + 255) / 256), dim3(256), 0, c->stream, d_pos, d_idx, n_tris,
-                     (float4*)B.tri_mn, (float4*)B.tri_mx, (float4*)B.tri_c, B.order_in);
-  bvhb::BNode root;
-  std::memset(&root, 0, sizeof(root));
-  root.count = n_tris;
-  root.left = root.right = -1;
-  const uint32_t one = 1u;
-  HIP_TRY(c, hipMemcpyAsync(B.nodes, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(B.counters, &one, 4, hipMemcpyHostToDevice, c->stream));
-  std::vector<std::pair<uint32_t, uint32_t>> levels;  // (first BFS id, node count) per level: the ids of a level are contiguous
-  uint32_t n_active = 1, id0 = 0, total = 1;
-  bool big_possible = n_tris > bvhb::kBig;
-  int small_levels = 0;
   if (!c->bv_pinned) HIP_TRY(c, hipHostMalloc(&c->bv_pinned, 1 << 16, hipHostMallocDefault));
-  uint32_t* pinned_counter = (uint32_t*)c->bv_pinned;
-  bvhb::BNode* pinned_nodes = (bvhb::BNode*)((char*)c->bv_pinned + 64);
-  const uint32_t pinned_node_cap = (uint32_t)(((1 << 16) - 64) / sizeof(bvhb::BNode));
-  std::vector<bvhb::BNode> host_nodes_vec;
-  std::vector<bvhb::BigNode> big;
-  std::vector<bvhb::Chunk> chunks;
-  std::vector<uint32_t> small_ids;
-  while (n_active) {
-    levels.emplace_back(id0, n_active);
-    if (levels.size() > (size_t)n_tris + 1) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: the tree is deeper than its triangle count");
-    big.clear();
-    chunks.clear();
-    small_ids.clear();
-    if (big_possible) {
-      // the few nodes of the first levels: those above kBig triangles are cut into chunks and worked on by many workgroups
-      bvhb::BNode* host_nodes = pinned_nodes;
-      if (n_active > pinned_node_cap) {
-        host_nodes_vec.resize(n_active);
-        host_nodes = host_nodes_vec.data();
-      }
-      HIP_TRY(c, hipMemcpyAsync(host_nodes, B.nodes + id0, (size_t)n_active * sizeof(bvhb::BNode), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      for (uint32_t i = 0; i < n_active; i++) {
-        if (host_nodes[i].count > bvhb::kBig) {
-          bvhb::BigNode N;
-          std::memset(&N, 0, sizeof(N));
-          N.id = id0 + i;
-          N.first = host_nodes[i].first;
-          N.count = host_nodes[i].count;
-          N.chunk0 = (uint32_t)chunks.size();
-          N.nchunks = (N.count + bvhb::kChunk - 1) / bvhb::kChunk;
-          for (int k = 0; k < 3; k++) N.box[k] = 0xffffffffu;
-          for (int bi = 0; bi < bvhb::kBins; bi++)
-            for (int k = 0; k < 3; k++) N.bin_box[bi][k] = 0xffffffffu;
-          for (uint32_t j = 0; j < N.nchunks; j++) chunks.push_back(bvhb::Chunk{(uint32_t)big.size(), j});
-          big.push_back(N);
-        } else {
-          small_ids.push_back(id0 + i);
-        }
-      }
-      if (big.empty()) big_possible = false;  // children are never larger than their parent
-    }
-    if (!big.empty()) {
-      const uint32_t nb = (uint32_t)big.size(), nc = (uint32_t)chunks.size();
-      if ((r = ensure_buffer(c, c->bv_big, (size_t)nb * sizeof(bvhb::BigNode) + (size_t)nc * (sizeof(bvhb::Chunk) + 16), false)) < 0) return r;
-      bvhb::BigNode* d_big = (bvhb::BigNode*)c->bv_big.ptr;
-      bvhb::Chunk* d_chunks = (bvhb::Chunk*)(d_big + nb);
-      uint32_t* d_cnt = (uint32_t*)(d_chunks + nc);
-      uint32_t* d_base = d_cnt + 2 * (size_t)nc;
-      HIP_TRY(c, hipMemcpyAsync(d_big, big.data(), (size_t)nb * sizeof(bvhb::BigNode), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(d_chunks, chunks.data(), (size_t)nc * sizeof(bvhb::Chunk), hipMemcpyHostToDevice, c->stream));
-      const dim3 gn((nb + 63) / 64), gc(nc);
-      if (id0 == 0)  // only the root reduces its box; children get theirs from the parent's sweep
-        hipLaunchKernelGGL(bvhb::k_big_bounds, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
-      hipLaunchKernelGGL(bvhb::k_big_setup, gn, dim3(64), 0, c->stream, B, d_big, nb);
-      hipLaunchKernelGGL(bvhb::k_big_bin, gc, dim3(256), 0, c->stream, B, d_big, (const bvhb::Chunk*)d_chunks);
-      hipLaunchKernelGGL(bvhb::k_big_split, gn, dim3(64), 0, c->stream, d_big, nb);
-      hipLaunchKernelGGL(bvhb::k_big_count, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks, d_cnt);
-      hipLaunchKernelGGL(bvhb::k_big_scan, gn, dim3(64), 0, c->stream, d_big, nb, (const uint32_t*)d_cnt, d_base);
-      hipLaunchKernelGGL(bvhb::k_big_scatter, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks,
-                         (const uint32_t*)d_cnt, (const uint32_t*)d_base);
-      hipLaunchKernelGGL(bvhb::k_big_swap, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
-      hipLaunchKernelGGL(bvhb::k_big_copy, gc, dim3(256), 0, c->stream, B, (const bvhb::BigNode*)d_big, (const bvhb::Chunk*)d_chunks);
-      if (!small_ids.empty()) {
-        HIP_TRY(c, hipMemcpyAsync(d_ids, small_ids.data(), small_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(bvhb::k_level<256>, dim3((uint32_t)small_ids.size()), dim3(256), 0, c->stream, B, (const uint32_t*)d_ids, 0u,
-                           (uint32_t)small_ids.size());
-      }
-    } else if (small_levels++ < 3) {
-      hipLaunchKernelGGL(bvhb::k_level<256>, dim3(n_active), dim3(256), 0, c->stream, B, (const uint32_t*)nullptr, id0, n_active);
-    } else {
-      // deep levels: tens of thousands of nodes of a few dozen triangles, and the sweep of a node is one lane's work —
-      // one wave per node keeps four times as many nodes in flight per CU
-      hipLaunchKernelGGL(bvhb::k_level<64>, dim3(n_active), dim3(64), 0, c->stream, B, (const uint32_t*)nullptr, id0, n_active);
-    }
-    HIP_TRY(c, hipMemcpyAsync(pinned_counter, B.counters, 4, hipMemcpyDeviceToHost, c->stream));
+  bvhb::Ctl* ctl = (bvhb::Ctl*)c->bv_pinned;
+  // as many levels as the last build of a mesh of this size needed (+ 2), else a guess; a deeper tree is built again
+  uint32_t levels = (c->bv_levels && c->bv_last_tris == n_tris) ? c->bv_levels + 2u : blas_guess_levels(n_tris);
+  uint32_t big_levels = (c->bv_levels && c->bv_last_tris == n_tris) ? c->bv_big_levels : blas_guess_big_levels(n_tris);
+  bvhb::Build B;
+  for (;;) {
+    levels = std::min<uint32_t>(levels, bvhb::kMaxLevels);
+    if ((r = blas_enqueue(c, d_pos, d_idx, n_tris, levels, big_levels, (float4*)c->bv_out.ptr, nullptr, 0u, B)) < 0) return r;
+    HIP_TRY(c, hipMemcpyAsync(ctl, B.ctl, sizeof(bvhb::Ctl), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    const uint32_t next_total = *pinned_counter;
-    if (next_total > max_nodes || next_total < total) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
-    id0 = total;
-    n_active = next_total - total;
-    total = next_total;
-    std::swap(B.order_in, B.order_out);
+    if (ctl->cnt[levels] == 0u) break;
+    if (levels >= bvhb::kMaxLevels) return fail(c, RT_ERR_INVALID, "rt_build_blas: the tree is deeper than 1024 levels");
+    levels = levels * 2u + 8u;
   }
+  const uint32_t total = ctl->n_nodes;
+  if (total > 2 * n) return fail(c, RT_ERR_INTERNAL, "rt_build_blas: node bookkeeping broke");
   if (total > nodes_cap) return fail(c, RT_ERR_INVALID, "rt_build_blas: node buffer too small");
-  for (size_t l = levels.size(); l-- > 0;)
-    hipLaunchKernelGGL(bvhb::k_sizes, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, B.nodes, levels[l].first, levels[l].second);
-  for (size_t l = 0; l < levels.size(); l++)
-    hipLaunchKernelGGL(bvhb::k_preorder, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, B.nodes, levels[l].first, levels[l].second);
-  hipLaunchKernelGGL(bvhb::k_emit, dim3((total + 255) / 256), dim3(256), 0, c->stream, (const bvhb::BNode*)B.nodes, total, (float4*)c->bv_out.ptr);
-  HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(nodes_out, c->bv_out.ptr, (size_t)total * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(order_out, B.order_final, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *n_nodes_out = total;
-  c->bv_levels = (uint32_t)levels.size();
+  uint32_t depth = 0;
+  while (depth < bvhb::kMaxLevels && ctl->cnt[depth]) depth++;
+  c->bv_levels = depth;
+  c->bv_big_levels = ctl->big_levels;
+  c->bv_last_tris = n_tris;
+  return RT_OK;
+}
+
+// ---- device-resident World::update(t): include/mi355rt.h rt_world_update, kernels in csrc/world_update.hip.h ----
+// (Re)build the static side: the skinning input, index lists and attribute rows of every geometry and the instance list
+// go to the device once per static_epoch; the scene buffers are sized for the whole world.
+static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
+  auto& W = c->world;
+  W.valid = false;
+  if (!f->n_instances || !f->instances || (f->n_geometries && !f->geometries))
+    return fail(c, RT_ERR_INVALID, "rt_world_update: empty scene description");
+  const uint32_t G = f->n_geometries, N = f->n_instances;
+  // layout of the static buffer (256-byte aligned arrays) and the world's totals
+  size_t bytes = 0;
+  auto take = [&](size_t n) { size_t o = bytes; bytes += (n + 255) & ~(size_t)255; return o; };
+  struct Off { size_t pos, nrm, uv, joints, weights, idx, attr; };
+  std::vector<Off> off(G);
+  W.geoms.assign(G, wu::Geom());
+  uint64_t verts = 0, tris = 0, lights = 0;
+  std::vector<uint32_t> em_count(G, 0u);
+  for (uint32_t g = 0; g < G; g++) {
+    const rt_world_geometry& d = f->geometries[g];
+    if (d.n_verts && (!d.positions || !d.normals || !d.joints || !d.weights)) return fail(c, RT_ERR_INVALID, "rt_world_update: null vertex array");
+    if (d.n_tris && (!d.indices || !d.attributes)) return fail(c, RT_ERR_INVALID, "rt_world_update: null triangle array");
+    if (d.n_uvs > d.n_verts || (d.n_uvs && !d.uvs)) return fail(c, RT_ERR_INVALID, "rt_world_update: bad uv array");
+    if (d.n_verts && !d.n_tris) return fail(c, RT_ERR_INVALID, "rt_world_update: a geometry with vertices and no triangles is not supported on the device");
+    if (d.n_tris > (1u << 28)) return fail(c, RT_ERR_INVALID, "rt_world_update: too many triangles for the 29-bit leaf field");
+    if (d.skin >= 0 && (uint32_t)d.skin >= f->n_skins) return fail(c, RT_ERR_INVALID, "rt_world_update: skin index out of range");
+    for (size_t k = 0; k < (size_t)d.n_tris * 3; k++)
+      if (d.indices[k] >= d.n_verts) return fail(c, RT_ERR_INVALID, "rt_world_update: vertex index out of range");
+    for (uint32_t t = 0; t < d.n_tris; t++) em_count[g] += std::fabs(d.attributes[(size_t)t * 16 + 3] - 3.0f) < 1e-6f ? 1u : 0u;
+    off[g].pos = take((size_t)d.n_verts * 12);
+    off[g].nrm = take((size_t)d.n_verts * 12);
+    off[g].uv = take((size_t)d.n_uvs * 8);
+    off[g].joints = take((size_t)d.n_verts * 16);
+    off[g].weights = take((size_t)d.n_verts * 16);
+    off[g].idx = take((size_t)d.n_tris * 12);
+    off[g].attr = take((size_t)d.n_tris * 64);
+    wu::Geom& D = W.geoms[g];
+    D.n_verts = d.n_verts;
+    D.n_uvs = d.n_uvs;
+    D.n_tris = d.n_tris;
+    D.v_offset = (uint32_t)verts;
+    D.topo_start = (uint32_t)tris;
+    D.skinned = d.skin >= 0 ? 1u : 0u;
+    D.joint_first = D.n_joints = 0u;   // per frame (skin_first)
+    D.em_count = em_count[g];
+    D.em_first = 0u;
+    D.pad0 = (uint32_t)(d.skin >= 0 ? d.skin : 0);   // the skin's index, for the per-frame joint range
+    D.pad1 = 0u;
+    verts += d.n_verts;
+    tris += d.n_tris;
+  }
+  if (!verts || !tris) return fail(c, RT_ERR_INVALID, "rt_world_update: the world has no triangles");
+  if (verts > 0xfffffff0ull || tris > (1ull << 28)) return fail(c, RT_ERR_INVALID, "rt_world_update: world too large");
+  W.inst_geom.assign(N, 0u);
+  W.inst_scale2.assign(N, 1.0f);
+  for (uint32_t i = 0; i < N; i++) {
+    const rt_instance& I = f->instances[i];
+    if (I.instance_id >= G || !f->geometries[I.instance_id].n_tris)
+      return fail(c, RT_ERR_INVALID, "rt_world_update: an instance of a missing or empty geometry is not supported on the device");
+    W.inst_geom[i] = I.instance_id;
+    lights += em_count[I.instance_id];
+    const float* m = I.transform;   // column-major 4x4: squared linear scale = |det(M3x3)|^(2/3), as in rt_upload
+    const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[6] * m[9]) - (double)m[4] * ((double)m[1] * m[10] - (double)m[2] * m[9]) +
+                       (double)m[8] * ((double)m[1] * m[6] - (double)m[2] * m[5]);
+    double s2 = std::pow(std::fabs(det), 2.0 / 3.0);
+    if (!(s2 > 0.0) || !std::isfinite(s2)) s2 = 1.0;
+    W.inst_scale2[i] = (float)s2;
+  }
+  if (lights > 0x7fffffffull) return fail(c, RT_ERR_INVALID, "rt_world_update: too many lights");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r;
+  if ((r = ensure_buffer(c, W.stat, std::max<size_t>(bytes, 256), false)) < 0) return r;
+  char* base = (char*)W.stat.ptr;
+  uint32_t em_first = 0, max_tris = 0;
+  std::vector<wu::GeomRow> rows(G);
+  for (uint32_t g = 0; g < G; g++) {
+    const rt_world_geometry& d = f->geometries[g];
+    wu::Geom& D = W.geoms[g];
+    auto put = [&](size_t o, const void* src, size_t n) -> hipError_t {
+      return n ? hipMemcpyAsync(base + o, src, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    };
+    HIP_TRY(c, put(off[g].pos, d.positions, (size_t)d.n_verts * 12));
+    HIP_TRY(c, put(off[g].nrm, d.normals, (size_t)d.n_verts * 12));
+    HIP_TRY(c, put(off[g].uv, d.uvs, (size_t)d.n_uvs * 8));
+    HIP_TRY(c, put(off[g].joints, d.joints, (size_t)d.n_verts * 16));
+    HIP_TRY(c, put(off[g].weights, d.weights, (size_t)d.n_verts * 16));
+    HIP_TRY(c, put(off[g].idx, d.indices, (size_t)d.n_tris * 12));
+    HIP_TRY(c, put(off[g].attr, d.attributes, (size_t)d.n_tris * 64));
+    D.pos3 = (const float*)(base + off[g].pos);
+    D.nrm3 = (const float*)(base + off[g].nrm);
+    D.uv2 = (const float*)(base + off[g].uv);
+    D.joints = (const uint32_t*)(base + off[g].joints);
+    D.weights = (const float*)(base + off[g].weights);
+    D.idx = (const uint32_t*)(base + off[g].idx);
+    D.attr = (const float*)(base + off[g].attr);
+    D.em_first = em_first;
+    em_first += D.em_count;
+    max_tris = std::max(max_tris, D.n_tris);
+    rows[g] = wu::GeomRow{D.n_tris, D.topo_start, D.em_count, D.em_first};
+  }
+  const uint32_t n_tlas = 2u * N - 1u;
+  if ((r = ensure_buffer(c, W.raw_inst, (size_t)N * sizeof(rt_instance), false)) < 0) return r;
+  HIP_TRY(c, hipMemcpyAsync(W.raw_inst.ptr, f->instances, (size_t)N * sizeof(rt_instance), hipMemcpyHostToDevice, c->stream));
+  if ((r = ensure_buffer(c, W.geom_rows, std::max<size_t>(16, (size_t)G * sizeof(wu::GeomRow)), false)) < 0) return r;
+  HIP_TRY(c, hipMemcpyAsync(W.geom_rows.ptr, rows.data(), (size_t)G * sizeof(wu::GeomRow), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the sources above belong to the caller
+  if ((r = ensure_buffer(c, W.node_base, ((size_t)G + 1) * 4, false)) < 0) return r;
+  if ((r = ensure_buffer(c, W.stats, std::max<size_t>(64, (size_t)G * 16 + 16), false)) < 0) return r;
+  if ((r = ensure_buffer(c, W.em_flag, (size_t)max_tris * 4, false)) < 0) return r;
+  if ((r = ensure_buffer(c, W.em_blk, ((size_t)max_tris / 1024 + 2) * 4, false)) < 0) return r;
+  if ((r = ensure_buffer(c, W.em_list, std::max<size_t>(16, (size_t)em_first * 4), false)) < 0) return r;
+  // k_tlas scratch: box 6, ctr 3, ord 1, ord2 1, seg 3, skey 18, sinfo 2, light_off 1 words per instance + 4 status words
+  if ((r = ensure_buffer(c, W.tlas_scratch, ((size_t)N * 35 + 4) * 4, false)) < 0) return r;
+  // the renderer's scene buffers, sized for the whole world (node array: TLAS + at most 2 n - 1 nodes per geometry)
+  size_t max_nodes = n_tlas;
+  for (uint32_t g = 0; g < G; g++) max_nodes += W.geoms[g].n_tris ? 2 * (size_t)W.geoms[g].n_tris - 1 : 0;
+  bool grew = false;
+  auto scene_buffer = [&](DeviceBuffer& b, size_t n) -> int {
+    int rr = ensure_buffer(c, b, n, true);
+    if (rr > 0) grew = true;
+    return rr;
+  };
+  if ((r = scene_buffer(c->pos, (size_t)verts * 16)) < 0) return r;
+  if ((r = scene_buffer(c->nrm, (size_t)verts * 16)) < 0) return r;
+  if ((r = scene_buffer(c->uv, (size_t)verts * 8)) < 0) return r;
+  if ((r = scene_buffer(c->topology, (size_t)tris * sizeof(rt_topology))) < 0) return r;
+  if ((r = scene_buffer(c->nodes, max_nodes * sizeof(rt_node))) < 0) return r;
+  if ((r = scene_buffer(c->instances, (size_t)N * sizeof(rt_instance))) < 0) return r;
+  if ((r = scene_buffer(c->lights, std::max<size_t>(16, (size_t)lights * sizeof(rt_light_ref)))) < 0) return r;
+  if ((r = ensure_buffer(c, c->draw_commands, (size_t)N * 16, false)) < 0) return r;
+  if (!W.ev0) HIP_TRY(c, hipEventCreate(&W.ev0));
+  if (!W.ev1) HIP_TRY(c, hipEventCreate(&W.ev1));
+  W.levels.assign(G, 0u);
+  W.big_levels.assign(G, 0u);
+  for (uint32_t g = 0; g < G; g++) {
+    W.levels[g] = blas_guess_levels(W.geoms[g].n_tris);
+    W.big_levels[g] = blas_guess_big_levels(W.geoms[g].n_tris);
+  }
+  W.n_verts = (uint32_t)verts;
+  W.n_tris = (uint32_t)tris;
+  W.n_lights = (uint32_t)lights;
+  W.n_tlas = n_tlas;
+  W.n_inst = N;
+  uint32_t* ts = (uint32_t*)W.tlas_scratch.ptr;
+  wu::TlasArgs& A = W.tlas;
+  A.raw = (const float4*)W.raw_inst.ptr;
+  A.geoms = (const wu::GeomRow*)W.geom_rows.ptr;
+  A.node_base = (const uint32_t*)W.node_base.ptr;
+  A.box = (float*)ts;
+  A.ctr = (float*)(ts + (size_t)N * 6);
+  A.ord = ts + (size_t)N * 9;
+  A.ord2 = ts + (size_t)N * 10;
+  A.seg = ts + (size_t)N * 11;
+  A.skey = ts + (size_t)N * 14;
+  A.sinfo = ts + (size_t)N * 32;
+  A.light_off = ts + (size_t)N * 34;
+  A.status = ts + (size_t)N * 35;
+  A.n_inst = N;
+  A.n_tlas = n_tlas;
+  A.n_lights = (uint32_t)lights;
+  A.pad = 0;
+  W.epoch = f->static_epoch;
+  W.valid = true;
+  return grew ? RT_REALLOCATED : RT_OK;
+}
+
+int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
+  if (!c || !f) return RT_ERR_INVALID;
+  auto& W = c->world;
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r, ret = RT_OK;
+  if (!W.valid || W.epoch != f->static_epoch) {
+    if ((r = world_make_static(c, f)) < 0) return r;
+    ret = r;
+  }
+  const uint32_t G = (uint32_t)W.geoms.size(), N = W.n_inst;
+  if (f->n_geometries != G || f->n_instances != N) return fail(c, RT_ERR_INVALID, "rt_world_update: the scene changed under an unchanged static_epoch");
+  // this frame's joint matrices
+  const uint32_t n_joints = f->n_skins ? f->skin_first[f->n_skins] : 0u;
+  if (n_joints && !f->joint_mats) return fail(c, RT_ERR_INVALID, "rt_world_update: null joint matrices");
+  const size_t joint_bytes = (size_t)n_joints * 64;
+  if ((r = ensure_buffer(c, W.joints, std::max<size_t>(64, joint_bytes), false)) < 0) return r;
+  // pinned staging: the end-of-update read-back (node_base, per-geometry stats, k_tlas status, TLAS root), then the joints
+  const size_t rb_bytes = (((size_t)G + 1) * 4 + (size_t)G * 16 + 16 + 32 + 4095) & ~(size_t)4095;
+  if (rb_bytes + joint_bytes > W.pinned_bytes) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (W.pinned) (void)hipHostFree(W.pinned);
+    W.pinned = nullptr;
+    W.pinned_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&W.pinned, (rb_bytes + joint_bytes) * 2 + 65536, hipHostMallocDefault));
+    W.pinned_bytes = (rb_bytes + joint_bytes) * 2 + 65536;
+  }
+  char* pinned_rb = (char*)W.pinned;
+  char* pinned_joints = (char*)W.pinned + rb_bytes;
+  for (uint32_t g = 0; g < G; g++) {
+    wu::Geom& D = W.geoms[g];
+    if (D.skinned) {
+      const uint32_t si = D.pad0;
+      D.joint_first = f->skin_first[si];
+      D.n_joints = f->skin_first[si + 1] - f->skin_first[si];
+    }
+  }
+  uint32_t* d_node_base = (uint32_t*)W.node_base.ptr;
+  uint32_t* d_stats = (uint32_t*)W.stats.ptr;
+  float4* nodes = (float4*)c->nodes.ptr;
+  for (int attempt = 0;; attempt++) {
+    HIP_TRY(c, hipEventRecord(W.ev0, c->stream));
+    if (joint_bytes) {
+      std::memcpy(pinned_joints, f->joint_mats, joint_bytes);
+      HIP_TRY(c, hipMemcpyAsync(W.joints.ptr, pinned_joints, joint_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(d_node_base, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(W.tlas.status, 0, 16, c->stream));
+    for (uint32_t g = 0; g < G; g++) {
+      const wu::Geom& D = W.geoms[g];
+      if (!D.n_verts) {   // an empty geometry owns no nodes: the next one starts where this one would
+        HIP_TRY(c, hipMemcpyAsync(d_node_base + g + 1, d_node_base + g, 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_stats + 4 * (size_t)g, 0, 16, c->stream));
+        continue;
+      }
+      hipLaunchKernelGGL(wu::k_skin, dim3((D.n_verts + 255) / 256), dim3(256), 0, c->stream, D, (const float*)W.joints.ptr, (float4*)c->pos.ptr,
+                         (float4*)c->nrm.ptr, (float2*)c->uv.ptr);
+      bvhb::Build B;
+      if ((r = blas_enqueue(c, (const float4*)c->pos.ptr + D.v_offset, D.idx, D.n_tris, W.levels[g], W.big_levels[g], nodes + 2 * (size_t)W.n_tlas,
+                            d_node_base + g, D.topo_start, B)) < 0)
+        return r;
+      hipLaunchKernelGGL(wu::k_build_stats, dim3(1), dim3(1), 0, c->stream, (const bvhb::Ctl*)B.ctl, std::min<uint32_t>(W.levels[g], bvhb::kMaxLevels),
+                         d_stats + 4 * (size_t)g);
+      uint32_t* em_flag = D.em_count ? (uint32_t*)W.em_flag.ptr : nullptr;
+      hipLaunchKernelGGL(wu::k_topology, dim3((D.n_tris + 255) / 256), dim3(256), 0, c->stream, D, g, (const uint32_t*)B.order_final,
+                         (float4*)c->topology.ptr, em_flag);
+      if (D.em_count) {
+        const uint32_t n_blk = (D.n_tris + 1023u) / 1024u;
+        hipLaunchKernelGGL(bvhb::k_scan_blocks, dim3(n_blk), dim3(1024), 0, c->stream, (const uint32_t*)em_flag, D.n_tris, (uint32_t*)W.em_blk.ptr);
+        hipLaunchKernelGGL(bvhb::k_scan_top, dim3(1), dim3(1024), 0, c->stream, (uint32_t*)W.em_blk.ptr, n_blk, (bvhb::Ctl*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(wu::k_emissive_apply, dim3(n_blk), dim3(1024), 0, c->stream, D, (const uint32_t*)em_flag, (const uint32_t*)W.em_blk.ptr,
+                           (uint32_t*)W.em_list.ptr);
+      }
+    }
+    wu::TlasArgs A = W.tlas;
+    A.nodes = nodes;
+    A.inst_out = (float4*)c->instances.ptr;
+    A.draw_out = (uint4*)c->draw_commands.ptr;
+    hipLaunchKernelGGL(wu::k_tlas, dim3(1), dim3(1024), 0, c->stream, A);
+    if (W.n_lights)
+      hipLaunchKernelGGL(wu::k_lights, dim3(N), dim3(256), 0, c->stream, A, (const uint32_t*)W.em_list.ptr, (uint2*)c->lights.ptr);
+    HIP_TRY(c, hipGetLastError());
+    // one read-back: where every BLAS starts, whether every tree was finished, the TLAS root
+    uint32_t* rb_base = (uint32_t*)pinned_rb;
+    uint32_t* rb_stats = rb_base + G + 1;
+    uint32_t* rb_status = rb_stats + 4 * (size_t)G;
+    float* rb_root = (float*)(rb_status + 4);
+    HIP_TRY(c, hipMemcpyAsync(rb_base, d_node_base, ((size_t)G + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (G) HIP_TRY(c, hipMemcpyAsync(rb_stats, d_stats, (size_t)G * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rb_status, W.tlas.status, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rb_root, nodes, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(W.ev1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool again = false;
+    for (uint32_t g = 0; g < G; g++) {
+      if (!W.geoms[g].n_verts) continue;
+      const uint32_t* st = rb_stats + 4 * (size_t)g;
+      if (st[0]) {   // deeper than launched: build again with more levels
+        if (W.levels[g] >= bvhb::kMaxLevels) return fail(c, RT_ERR_INVALID, "rt_world_update: a BLAS is deeper than 1024 levels");
+        W.levels[g] = std::min<uint32_t>(bvhb::kMaxLevels, W.levels[g] * 2u + 8u);
+        again = true;
+      } else {
+        W.levels[g] = std::min<uint32_t>(bvhb::kMaxLevels, st[1] + 2u);
+        W.big_levels[g] = st[2];
+      }
+    }
+    if (again) {
+      if (attempt >= 8) return fail(c, RT_ERR_INTERNAL, "rt_world_update: BLAS depth did not settle");
+      continue;
+    }
+    if (rb_status[0]) return fail(c, RT_ERR_INVALID, "rt_world_update: an instance box has a NaN centre; the host path defines this update");
+    if (rb_status[1] != W.n_lights) return fail(c, RT_ERR_INTERNAL, "rt_world_update: light count mismatch");
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, W.ev0, W.ev1) == hipSuccess) W.last_ms = ms;
+    // ---- host bookkeeping, what rt_upload / rt_upload_geometry / rt_upload_bvh would have set
+    const uint32_t n_blas = rb_base[G];
+    c->n_verts = c->vertex_count = W.n_verts;
+    c->n_tris = W.n_tris;
+    c->n_instances = N;
+    c->n_lights = W.n_lights;
+    c->blas_offset = W.n_tlas;
+    c->n_nodes = W.n_tlas + n_blas;
+    c->pos.size = (size_t)W.n_verts * 16;
+    c->nodes.size = (size_t)c->n_nodes * sizeof(rt_node);
+    c->draw_commands_host.clear();   // made on the device (rt_world_read gives them)
+    uint32_t inner = N - 1u;
+    for (uint32_t g = 0; g < G; g++) {
+      const uint32_t cnt = rb_base[g + 1] - rb_base[g];
+      if (cnt) inner += (cnt - 1u) / 2u;
+    }
+    c->n_pairs = inner;
+    std::memset(&c->troot, 0, sizeof(c->troot));
+    for (int k = 0; k < 3; k++) {
+      c->troot.lo[k] = rb_root[k];
+      c->troot.hi[k] = rb_root[4 + k];
+    }
+    {
+      uint32_t w7;
+      std::memcpy(&w7, &rb_root[7], 4);
+      c->troot.word = w7 == 0u ? RT_PAIR_INNER : w7;
+    }
+    const std::vector<uint32_t> old_roots = c->blas_roots;
+    c->blas_roots.resize(N);
+    for (uint32_t i = 0; i < N; i++) c->blas_roots[i] = rb_base[W.inst_geom[i]];
+    std::sort(c->blas_roots.begin(), c->blas_roots.end());
+    c->blas_roots.erase(std::unique(c->blas_roots.begin(), c->blas_roots.end()), c->blas_roots.end());
+    c->root_w_host.assign(c->blas_roots.size(), 0.0f);
+    for (uint32_t i = 0; i < N; i++) {
+      const size_t k = std::lower_bound(c->blas_roots.begin(), c->blas_roots.end(), rb_base[W.inst_geom[i]]) - c->blas_roots.begin();
+      c->root_w_host[k] += W.inst_scale2[i];
+    }
+    // the arrays were made by this library from an index-checked description: no validation pass; the derived passes
+    // of prepare_scene read the sorted roots from val_roots
+    if ((r = ensure_buffer(c, c->val_roots, std::max<size_t>(4, c->blas_roots.size() * 4), false)) < 0) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->val_roots.ptr, c->blas_roots.data(), c->blas_roots.size() * 4, hipMemcpyHostToDevice, c->stream));
+    c->validate_dirty = false;
+    c->scene_valid = true;
+    c->tris_dirty = c->inst_dirty = c->lights_dirty = c->nodes_dirty = c->pairs_dirty = c->roots_dirty = true;
+    return ret;
+  }
+}
+
+double rt_world_last_ms(const rt_ctx* c) { return c ? c->world.last_ms : 0.0; }
+
+// the bridge arrays as the device update left them (tests; a host that wants them back)
+int rt_world_read(rt_ctx* c, int which, void* out, size_t cap_bytes, size_t* bytes_out) {
+  if (!c || !bytes_out) return RT_ERR_INVALID;
+  *bytes_out = 0;
+  if (!c->world.valid) return fail(c, RT_ERR_NOT_READY, "rt_world_read: no device-resident world");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const void* src = nullptr;
+  size_t n = 0;
+  switch (which) {
+    case RT_WORLD_VERTICES: src = c->pos.ptr; n = (size_t)c->n_verts * 16; break;
+    case RT_WORLD_NORMALS: src = c->nrm.ptr; n = (size_t)c->n_verts * 16; break;
+    case RT_WORLD_UVS: src = c->uv.ptr; n = (size_t)c->n_verts * 8; break;
+    case RT_WORLD_TOPOLOGY: src = c->topology.ptr; n = (size_t)c->n_tris * sizeof(rt_topology); break;
+    case RT_WORLD_TLAS: src = c->nodes.ptr; n = (size_t)c->blas_offset * sizeof(rt_node); break;
+    case RT_WORLD_BLAS: src = (const char*)c->nodes.ptr + (size_t)c->blas_offset * sizeof(rt_node); n = (size_t)(c->n_nodes - c->blas_offset) * sizeof(rt_node); break;
+    case RT_WORLD_INSTANCES: src = c->instances.ptr; n = (size_t)c->n_instances * sizeof(rt_instance); break;
+    case RT_WORLD_LIGHTS: src = c->lights.ptr; n = (size_t)c->n_lights * sizeof(rt_light_ref); break;
+    case RT_WORLD_DRAW_COMMANDS: src = c->draw_commands.ptr; n = (size_t)c->n_instances * 16; break;
+    default: return fail(c, RT_ERR_INVALID, "rt_world_read: unknown array");
+  }
+  *bytes_out = n;
+  if (!out) return RT_OK;
+  if (cap_bytes < n) return fail(c, RT_ERR_INVALID, "rt_world_read: buffer too small");
+  if (n) HIP_TRY(c, hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RT_OK;
 }
 

@@ -18,6 +18,7 @@
 #include "../../../include/mi355rt_layout.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1117,6 +1118,11 @@ struct ms_world {
   // optional BLAS builder hook (ms_world_set_blas_builder): the GPU builder of libmi355rt.so
   ms_blas_builder blas_hook = nullptr;
   void* blas_hook_user = nullptr;
+  // optional device updater (ms_world_set_device_updater): rt_world_update of libmi355rt.so
+  ms_device_updater device_hook = nullptr;
+  void* device_hook_user = nullptr;
+  uint64_t static_epoch = 0;            // names the static scene description handed to the updater
+  bool device_resident = false;         // the last update ran on the device: the host bridge arrays were not refreshed
 };
 
 static thread_local std::string g_last_error;
@@ -1304,6 +1310,72 @@ struct PhaseTimer {  // MS_PROFILE=1: per-phase wall time of world_update on std
   }
 };
 
+// rebuilder.rs:40-47: the joint matrices of one skin, global(joint) * inverse_bind
+static void skin_joint_mats(const GSkin& skin, const std::vector<M4>& globals, std::vector<M4>& out) {
+  for (size_t k = 0; k < skin.joints.size() && k < skin.inverse_bind.size(); k++)
+    out.push_back(m4_mul(skin.joints[k] < globals.size() ? globals[skin.joints[k]] : m4_identity(), skin.inverse_bind[k]));
+}
+
+// The device half of update(t) (ms_world_set_device_updater): describe the scene and this frame's joint matrices to the
+// updater.  false = it refused or failed; the caller then runs the host path.
+static bool device_update(ms_world& w, const std::vector<M4>& globals) {
+  std::vector<rt_world_geometry> geos(w.scene.geometries.size());
+  for (size_t gi = 0; gi < geos.size(); gi++) {
+    const Geometry& g = w.scene.geometries[gi];
+    rt_world_geometry& d = geos[gi];
+    std::memset(&d, 0, sizeof(d));
+    d.positions = g.positions.empty() ? nullptr : &g.positions[0].x;
+    d.normals = g.normals.empty() ? nullptr : &g.normals[0].x;
+    d.uvs = g.uvs.empty() ? nullptr : &g.uvs[0].x;
+    d.joints = g.joints.data();
+    d.weights = g.weights.data();
+    d.indices = g.indices.data();
+    d.attributes = g.attributes.data();
+    d.n_verts = (uint32_t)g.positions.size();
+    d.n_uvs = (uint32_t)std::min(g.uvs.size(), g.positions.size());
+    d.n_tris = (uint32_t)(g.indices.size() / 3);
+    d.skin = (g.skin_index >= 0 && (size_t)g.skin_index < w.gltf.skins.size()) ? (int32_t)g.skin_index : -1;
+    if (g.normals.size() < g.positions.size() || g.joints.size() < g.positions.size() * 4 ||
+        g.weights.size() < g.positions.size() * 4 || g.attributes.size() < (size_t)d.n_tris * 16) {
+      g_last_error = "device updater: geometry " + std::to_string(gi) + " has short attribute arrays; host update used";
+      return false;
+    }
+  }
+  std::vector<rt_instance> inst(w.raw_instances.size());
+  for (size_t i = 0; i < inst.size(); i++) {
+    const RawInstance& r = w.raw_instances[i];
+    std::memcpy(inst[i].transform, r.transform.c, 64);
+    std::memcpy(inst[i].inverse, r.inverse.c, 64);
+    inst[i].blas_node_offset = 0;
+    inst[i].attr_offset = r.attr_offset;
+    inst[i].instance_id = r.instance_id;
+    inst[i].pad = r.pad;
+  }
+  std::vector<uint32_t> skin_first(w.gltf.skins.size() + 1, 0u);
+  std::vector<M4> mats;
+  for (size_t si = 0; si < w.gltf.skins.size(); si++) {
+    skin_first[si] = (uint32_t)mats.size();
+    skin_joint_mats(w.gltf.skins[si], globals, mats);
+  }
+  skin_first[w.gltf.skins.size()] = (uint32_t)mats.size();
+  rt_world_frame f;
+  std::memset(&f, 0, sizeof(f));
+  f.static_epoch = w.static_epoch;
+  f.n_geometries = (uint32_t)geos.size();
+  f.n_instances = (uint32_t)inst.size();
+  f.n_skins = (uint32_t)w.gltf.skins.size();
+  f.geometries = geos.data();
+  f.instances = inst.data();
+  f.skin_first = skin_first.data();
+  f.joint_mats = mats.empty() ? nullptr : &mats[0].c[0][0];
+  const int rc = w.device_hook(w.device_hook_user, &f);
+  if (rc < 0) {
+    g_last_error = "device updater failed (" + std::to_string(rc) + "); this update ran on the host";
+    return false;
+  }
+  return true;
+}
+
 static void world_update(ms_world& w, float time = 0.0f) {
   PhaseTimer pt;
   // --- lib.rs:149-184: animation, then global transforms of the scene graph ---
@@ -1315,6 +1387,22 @@ static void world_update(ms_world& w, float time = 0.0f) {
   std::vector<M4> globals;
   update_globals(w, globals);
   pt.lap(0);
+
+  // lib.rs:196-204 (quirk kept): every instance after the first is overwritten with rotY(pi) * scale(0.7).  Done before
+  // anything reads the transforms; the result does not depend on the frame.
+  if (!w.scene.keep_instance_transforms)
+    for (size_t i = 1; i < w.raw_instances.size(); i++) {
+      M4 t = m4_mul(m4_from_rotation_y(3.14159274101257324219f), m4_from_scale(v3(0.7f, 0.7f, 0.7f)));
+      w.raw_instances[i].transform = t;
+      w.raw_instances[i].inverse = m4_inverse(t);
+    }
+  w.device_resident = false;
+  if (w.device_hook) {
+    if (device_update(w, globals)) {
+      w.device_resident = true;
+      return;
+    }
+  }
 
   // --- rebuilder.rs:9-190: per geometry, vertices + BLAS + topology ---
   w.vertices.clear();
@@ -1346,9 +1434,7 @@ static void world_update(ms_world& w, float time = 0.0f) {
     // rebuilder.rs:36-91: linear blend skinning with joint matrices global(joint) * inverse_bind
     const GSkin* skin = (geo.skin_index >= 0 && (size_t)geo.skin_index < w.gltf.skins.size()) ? &w.gltf.skins[(size_t)geo.skin_index] : nullptr;
     std::vector<M4> joint_mats;
-    if (skin)
-      for (size_t k = 0; k < skin->joints.size() && k < skin->inverse_bind.size(); k++)
-        joint_mats.push_back(m4_mul(skin->joints[k] < globals.size() ? globals[skin->joints[k]] : m4_identity(), skin->inverse_bind[k]));
+    if (skin) skin_joint_mats(*skin, globals, joint_mats);
     parallel_for(n_geo_verts, [&](size_t lo_i, size_t hi_i) {
     for (size_t i = lo_i; i < hi_i; i++) {
       V3 p = geo.positions[i], n = geo.normals[i];
@@ -1444,12 +1530,6 @@ static void world_update(ms_world& w, float time = 0.0f) {
   // --- lib.rs:194-230: instance transforms, BLAS offsets, local boxes ---
   for (size_t i = 0; i < w.raw_instances.size(); i++) {
     RawInstance& inst = w.raw_instances[i];
-    if (i > 0 && !w.scene.keep_instance_transforms) {
-      // quirk kept: every instance after the first is overwritten with rotY(pi) * scale(0.7)
-      M4 t = m4_mul(m4_from_rotation_y(3.14159274101257324219f), m4_from_scale(v3(0.7f, 0.7f, 0.7f)));
-      inst.transform = t;
-      inst.inverse = m4_inverse(t);
-    }
     size_t gi = inst.instance_id;
     if (gi < w.blas_root_offsets.size()) {
       inst.blas_node_offset = w.blas_root_offsets[gi];
@@ -1555,6 +1635,8 @@ ms_world* ms_world_create_glb(const char* scene_name, const char* obj_source, co
     w->instance_blas_boxes.push_back(Aabb());
   }
   w->camera.assign(24, 0.0f);
+  static std::atomic<uint64_t> next_epoch{0};
+  w->static_epoch = ++next_epoch;   // unique per world: a renderer fed by two worlds in turn re-reads the static part
   world_update(*w);
   return w;
 }
@@ -1592,6 +1674,13 @@ void ms_world_set_blas_builder(ms_world* w, ms_blas_builder fn, void* user) {
   w->blas_hook = fn;
   w->blas_hook_user = user;
 }
+void ms_world_set_device_updater(ms_world* w, ms_device_updater fn, void* user) {
+  if (!w) return;
+  w->device_hook = fn;
+  w->device_hook_user = user;
+  if (!fn) w->device_resident = false;
+}
+int ms_world_device_resident(const ms_world* w) { return (w && w->device_resident) ? 1 : 0; }
 int ms_build_blas(const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
                   uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out) {
   if (!n_nodes_out) return -1;

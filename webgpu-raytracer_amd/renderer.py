@@ -174,6 +174,8 @@ def load_library(path=None):
                                     ctypes.POINTER(u32)]),
         "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
         "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]), "rt_set_lookahead": (i32, [vp, u32]),
+        "rt_world_update": (i32, [vp, vp]), "rt_world_last_ms": (ctypes.c_double, [vp]),
+        "rt_world_read": (i32, [vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
@@ -191,7 +193,8 @@ EXPORTED_SYMBOLS = (
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
     "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_read_traversal_nodes rt_debug_read_pairs "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
-    "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead").split()
+    "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead "
+    "rt_world_update rt_world_last_ms rt_world_read").split()
 
 
 def _ptr(a):
@@ -286,6 +289,25 @@ class WebGPURenderer:
         self._check(self.L.rt_build_blas(self.ctx, _ptr(v), v.shape[0], _ptr(idx), n_tris, _ptr(nodes), nodes.shape[0],
                                          ctypes.byref(n_nodes), _ptr(order)), "buildBlas")
         return nodes[:n_nodes.value].copy(), order[:n_tris].copy()
+
+    # the bridge arrays of the device-resident world (rt_world_read): name -> (rt_world_array, dtype, row width)
+    _WORLD_ARRAYS = {"vertices": (0, np.float32, 4), "normals": (1, np.float32, 4), "uvs": (2, np.float32, 2),
+                     "mesh_topology": (3, np.uint32, 20), "tlas": (4, np.float32, 8), "blas": (5, np.float32, 8),
+                     "instances": (6, np.float32, 36), "lights": (7, np.uint32, 2), "draw_commands": (8, np.uint32, 4)}
+
+    def worldRead(self, name):
+        """One bridge array as the last device-resident update(t) left it in HBM (flat, the bridge getter's dtype)."""
+        which, dtype, _ = self._WORLD_ARRAYS[name]
+        n = ctypes.c_size_t()
+        self._check(self.L.rt_world_read(self.ctx, which, None, 0, ctypes.byref(n)), "worldRead(%s)" % name)
+        out = np.empty(n.value // 4, dtype=dtype)
+        if n.value:
+            self._check(self.L.rt_world_read(self.ctx, which, _ptr(out), out.nbytes, ctypes.byref(n)), "worldRead(%s)" % name)
+        return out
+
+    def worldLastMs(self):
+        """GPU stream time of the last device-resident update(t) (ms)."""
+        return float(self.L.rt_world_last_ms(self.ctx))
 
     def readTextureLayer(self, layer):
         out = np.empty((1024, 1024, 4), dtype=np.uint8)
@@ -466,6 +488,15 @@ def sync_world(renderer, bridge, width, height):
     if not bridge.hasNewData:
         return False
     rebind = False
+    if getattr(bridge, "deviceResident", False):
+        # update(t) ran inside the renderer (WorldBridge.setDeviceUpdater -> rt_world_update): every array is already
+        # where the kernels read it; only the camera uniforms and the accumulation restart remain of main.ts:133-163
+        bridge.hasNewGeometry = False
+        bridge.updateCamera(width, height)
+        renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount)
+        renderer.resetAccumulation()
+        bridge.hasNewData = False
+        return True
     rebind |= bool(renderer.updateCombinedBVH(bridge.tlas, bridge.blas))
     rebind |= bool(renderer.updateBuffer("instance", bridge.instances))
     rebind |= bool(renderer.updateBuffer("draw_commands", bridge.draw_commands))

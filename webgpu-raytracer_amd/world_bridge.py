@@ -54,6 +54,10 @@ def _load():
     lib.ms_world_encoded_texture.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.ms_world_set_blas_builder.restype = None
     lib.ms_world_set_blas_builder.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ms_world_set_device_updater.restype = None
+    lib.ms_world_set_device_updater.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ms_world_device_resident.restype = ctypes.c_int
+    lib.ms_world_device_resident.argtypes = [ctypes.c_void_p]
     lib.ms_world_texture_count.restype = ctypes.c_size_t
     lib.ms_world_texture_count.argtypes = [ctypes.c_void_p]
     lib.ms_world_texture_rgba.restype = ctypes.POINTER(ctypes.c_uint8)
@@ -74,6 +78,9 @@ class WorldBridge:
         self._cache = {}
         self._tex_blobs = {}
         self._blas_renderer = None
+        self._device_renderer = None
+        self._device_fn = None
+        self.deviceResident = False      # the last update(t) ran on the device: the arrays below were NOT refreshed
         self.hasNewData = False
         self.hasNewGeometry = False
         self._last_wh = (-1, -1)
@@ -100,7 +107,9 @@ class WorldBridge:
         # a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
         self.loadWarning = self._lib.ms_last_error().decode() if glbData is not None else ""
         self._world = w
+        self.deviceResident = False
         self._apply_blas_builder()
+        self._apply_device_updater()
         self._tex_blobs = {}
         self._last_wh = (-1, -1)
         self._refresh()
@@ -124,16 +133,48 @@ class WorldBridge:
             fn = ctypes.cast(r.L.rt_build_blas, ctypes.c_void_p)
             self._lib.ms_world_set_blas_builder(self._world, fn, r.ctx)
 
+    def setDeviceUpdater(self, renderer, fn=None):
+        """Run the whole per-frame half of update(t) on the GPU, inside `renderer`'s scene buffers (rt_world_update,
+        SURVEY.md §8f N1): skinning, BLAS builds, topology / light / draw-command packing, TLAS, instances.  update(t)
+        then only samples the animation and hands the joint matrices over; the host arrays behind the getters are not
+        refreshed (`deviceResident` is True, sync_world() uploads nothing) — renderer.worldRead(name) reads one back.
+        None restores the host path.  `fn` (tests): a ctypes callback with ms_device_updater's signature instead of
+        the renderer's rt_world_update."""
+        self._device_renderer = renderer
+        self._device_fn = fn
+        self._apply_device_updater()
+
+    def _apply_device_updater(self):
+        if not self._world:
+            return
+        r = self._device_renderer
+        if self._device_fn is not None:
+            self._lib.ms_world_set_device_updater(self._world, ctypes.cast(self._device_fn, ctypes.c_void_p), None)
+        elif r is None or not r.ctx:
+            self._lib.ms_world_set_device_updater(self._world, None, None)
+        else:
+            self._lib.ms_world_set_device_updater(self._world, ctypes.cast(r.L.rt_world_update, ctypes.c_void_p), r.ctx)
+
     # world-bridge.ts:141-145
     def update(self, time):
         if self._blas_renderer is not None and not self._blas_renderer.ctx:
             raise RuntimeError("the renderer set with setBlasBuilder() has been destroyed")
+        if self._device_renderer is not None and self._device_fn is None and not self._device_renderer.ctx:
+            raise RuntimeError("the renderer set with setDeviceUpdater() has been destroyed")
         self._lib.ms_world_update(self._world, float(time))
-        if self._blas_renderer is not None:
+        self.deviceResident = bool(self._lib.ms_world_device_resident(self._world))
+        self.deviceWarning = ""
+        if self._device_renderer is not None or self._device_fn is not None:
+            if not self.deviceResident:      # the device path refused this scene / frame: the host path ran, say why
+                self.deviceWarning = self._lib.ms_last_error().decode()
+                if self._device_renderer is not None and self._device_renderer.ctx:
+                    self.deviceWarning += ": " + self._device_renderer.L.rt_last_error(self._device_renderer.ctx).decode()
+        elif self._blas_renderer is not None:
             err = self._lib.ms_last_error().decode()
             if err:
                 raise RuntimeError(err)      # the GPU builder failed: no silent CPU result
-        self._refresh()
+        if not self.deviceResident:
+            self._refresh()
         self.hasNewData = True
         self.hasNewGeometry = True
 
