@@ -211,6 +211,9 @@ int rt_debug_clock_stamps(rt_ctx* ctx, uint64_t* out_pairs, uint32_t cap_pairs);
  * the original-index -> new-index table, and the per-instance BLAS roots (any pointer may be NULL).  Returns the node count. */
 int rt_debug_read_traversal_nodes(rt_ctx* ctx, float* tnodes_out, uint32_t* new_index_out, uint32_t* inst_root_out,
                                   uint32_t cap_nodes);
+/* Diagnostics of the last rt_build_blas: tree levels the breadth-first build went through (nodes of at most 64 triangles
+ * are finished inside one wave and do not count) | levels that held a node above 4 096 triangles << 16. */
+int rt_build_blas_levels(const rt_ctx* ctx);
 /* Device-resident World::update(t): derive EVERY bridge array of this frame on the GPU, inside the
  * renderer's own scene buffers, from the static scene description and the frame's joint matrices (rt_world_frame,
  * mi355rt_layout.h): linear-blend skinning (rebuilder.rs:36-91), the binned-SAH BLAS of every geometry (bvh/blas.rs,

@@ -50,13 +50,13 @@ struct BNode {  // breadth-first build record
   uint32_t count;
   int32_t left, right;   // BFS ids, -1 for a leaf
   uint32_t leftdepth;    // ancestors of which this node is in the LEFT subtree
-  uint32_t pad;
+  uint32_t gen;          // Build::gen of the build that made this record (the id space is not dense: k_emit skips the rest)
 };
 
 // Device-side bookkeeping of one build (zeroed by k_tri_boxes)
 struct Ctl {
   uint32_t n_big, n_chunks, n_small, big_levels;  // plan of the current large-node level; levels that had a node > kBig
-  uint32_t n_leaves, n_nodes, pad0, pad1;         // results (k_scan_top)
+  uint32_t n_leaves, n_nodes, n_sub, pad1;        // results (k_scan_top); ids handed to the in-wave subtrees (k_subtree)
   uint32_t base[kMaxLevels + 2];                  // first BFS id of every level
   uint32_t cnt[kMaxLevels + 2];                   // nodes of every level
 };
@@ -72,9 +72,11 @@ struct Build {
   uint8_t* bin_cache;    // bin of the triangle at each position, written by the bin pass of the level
   uint32_t* leaf_flag;   // 1 at every position a leaf starts at; scanned into LB (n + 1 entries) at the end
   uint32_t* small_ids;   // nodes <= kBig of a large-node level
-  BNode* nodes;
+  BNode* nodes;          // 4 n records: [0, 2n) ids of the level kernels, [2n, 4n) blocks of the in-wave subtrees
   Ctl* ctl;
+  uint32_t n_tris, gen;  // gen: stamp of this build's node records
 };
+constexpr uint32_t kSubtree = 64u;   // a node of at most this many triangles is finished by ONE wave (k_subtree)
 
 __device__ __forceinline__ uint32_t key_of(float f) {  // order-preserving: a < b  <=>  key(a) < key(b); -0 < +0
   const uint32_t b = __float_as_uint(f);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_tri_boxes(const float4* __restrict__ po
       r.count = n_tris;
       r.left = r.right = -1;
       r.leftdepth = 0u;
-      r.pad = 0u;
+      r.gen = B.gen;
     }
   }
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -279,9 +281,185 @@ __device__ __forceinline__ void make_children(const Build& B, uint32_t level, ui
   l.left = l.right = r.left = r.right = -1;
   l.leftdepth = ld + 1u;
   r.leftdepth = ld;
-  l.pad = r.pad = 0u;
+  l.gen = r.gen = B.gen;
   B.nodes[id].left = (int32_t)ids;
   B.nodes[id].right = (int32_t)(ids + 1u);
+}
+
+// A node of at most 64 triangles, finished by one wave without going back to the level loop: lane l holds the triangle at
+// position first + l (id, box, centre: 10 registers); every node of the subtree runs the same five steps as k_level on those
+// registers — bins by LDS atomics, the 16-lane sweep, the two-pointer partition as ballot ranks, the rotation — the
+// triangles change lanes through LDS, pending nodes wait on a small LDS stack, and node records / leaf ranges are
+// stored without anything being read back.  Ids come from a block of 2 count - 2 reserved with ONE atomic (the id
+// space is not dense; records carry the build's stamp).  Replaces the deepest ~8 levels of launches, whose nodes each
+// cost a chain of ten dependent global-memory round trips for a few dozen triangles.
+struct SubShared {
+  uint32_t bin_cnt[kBins];
+  uint32_t bin_box[kBins][6];
+  uint32_t tri[kSubtree][10];
+  uint32_t stack[kSubtree + 2][9];   // rel | cnt << 8, id, leftdepth, box
+  uint32_t pl[kSubtree], pr[kSubtree];
+};
+__device__ __forceinline__ void k_subtree(const Build& B, SubShared& S, uint32_t id, uint32_t first, uint32_t count, const uint32_t* order_in) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const float inf = __uint_as_float(0x7f800000u);
+  uint32_t t = 0;
+  float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf}, ce[3] = {0.0f, 0.0f, 0.0f};
+  if (lane < count) {
+    t = order_in[first + lane];
+    const float4 a = B.tri_mn[t], b = B.tri_mx[t], c = B.tri_c[t];
+    mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
+    mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+    ce[0] = c.x; ce[1] = c.y; ce[2] = c.z;
+  }
+  float rbox[6];
+  if (id == 0u) {   // the whole mesh: only the root reduces its triangles' boxes
+    uint32_t k[6] = {key_of(mn[0]), key_of(mn[1]), key_of(mn[2]), key_of(mx[0]), key_of(mx[1]), key_of(mx[2])};
+    if (lane >= count) { k[0] = k[1] = k[2] = 0xffffffffu; k[3] = k[4] = k[5] = 0u; }
+    for (int off = 32; off > 0; off >>= 1)
+      for (int c = 0; c < 6; c++) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)k[c], off, 64);
+        k[c] = c < 3 ? min(k[c], o) : max(k[c], o);
+      }
+    for (int c = 0; c < 6; c++) rbox[c] = float_of(k[c]);
+    if (lane == 0u)
+      for (int c = 0; c < 3; c++) {
+        B.nodes[0].mn[c] = rbox[c];
+        B.nodes[0].mx[c] = rbox[c + 3];
+      }
+  } else {
+    for (int c = 0; c < 3; c++) {
+      rbox[c] = B.nodes[id].mn[c];
+      rbox[c + 3] = B.nodes[id].mx[c];
+    }
+  }
+  uint32_t blk = 0;
+  if (lane == 0u) blk = atomicAdd(&B.ctl->n_sub, 2u * count - 2u);
+  const uint32_t id_base = 2u * B.n_tris + (uint32_t)__shfl((int)blk, 0, 64);
+  uint32_t next_local = 0u;
+  if (lane == 0u) {
+    S.stack[0][0] = 0u | (count << 8);
+    S.stack[0][1] = id;
+    S.stack[0][2] = B.nodes[id].leftdepth;
+    for (int c = 0; c < 6; c++) S.stack[0][3 + c] = __float_as_uint(rbox[c]);
+  }
+  uint32_t sp = 1u;
+  __syncthreads();
+  while (sp > 0u) {
+    sp--;
+    const uint32_t e0 = S.stack[sp][0], nid = S.stack[sp][1], ld = S.stack[sp][2];
+    float nb[6];
+    for (int c = 0; c < 6; c++) nb[c] = __uint_as_float(S.stack[sp][3 + c]);
+    const uint32_t rel0 = e0 & 255u, cnt = e0 >> 8;
+    const bool in_range = lane >= rel0 && lane < rel0 + cnt;
+    const float ex = nb[3] - nb[0], ey = nb[4] - nb[1], ez = nb[5] - nb[2];
+    const int axis = ey > ex ? 1 : ((ez > ex && ez > ey) ? 2 : 0);   // blas.rs:127-133
+    const float split_len = axis == 0 ? ex : (axis == 1 ? ey : ez);
+    bool leaf = cnt <= 4u || split_len < 1e-6f;
+    SahOut o;
+    uint32_t bin = 0u;
+    if (!leaf) {
+      if (lane < (uint32_t)kBins) {
+        S.bin_cnt[lane] = 0u;
+        for (int c = 0; c < 3; c++) {
+          S.bin_box[lane][c] = 0xffffffffu;
+          S.bin_box[lane][c + 3] = 0u;
+        }
+      }
+      __syncthreads();
+      if (in_range) {
+        bin = bin_of(axis == 0 ? ce[0] : (axis == 1 ? ce[1] : ce[2]), nb[axis], (float)kBins / split_len);
+        atomicAdd(&S.bin_cnt[bin], 1u);
+        for (int c = 0; c < 3; c++) {
+          atomicMin(&S.bin_box[bin][c], key_of(mn[c]));
+          atomicMax(&S.bin_box[bin][c + 3], key_of(mx[c]));
+        }
+      }
+      __syncthreads();
+      o = sah_split_wave(S.bin_cnt, S.bin_box, cnt);
+      leaf = o.leaf != 0;
+    }
+    if (leaf) {   // blas.rs:111-115
+      if (in_range) B.order_final[first + lane] = t;
+      if (lane == 0u) {
+        B.nodes[nid].left = -1;
+        B.nodes[nid].right = -1;
+        B.leaf_flag[first + rel0] = 1u;
+      }
+      __syncthreads();   // the stack entry and the bins were read by every lane before anything below rewrites them
+      continue;
+    }
+    // the two-pointer partition: the k-th misplaced element from the left changes places with the k-th from the right
+    const uint32_t L = o.L, R = cnt - L, rel = lane - rel0;
+    const bool bad_l = in_range && rel < L && bin > (uint32_t)o.split;
+    const bool bad_r = in_range && rel >= L && bin <= (uint32_t)o.split;
+    const unsigned long long m_l = __ballot(bad_l), m_r = __ballot(bad_r);
+    const unsigned long long below = lane ? (~0ull >> (64u - lane)) : 0ull, above = lane < 63u ? (~0ull << (lane + 1u)) : 0ull;
+    const uint32_t rank_l = (uint32_t)__builtin_popcountll(m_l & below), rank_r = (uint32_t)__builtin_popcountll(m_r & above);
+    if (bad_l) S.pl[rank_l] = lane;
+    if (bad_r) S.pr[rank_r] = lane;
+    __syncthreads();
+    uint32_t pos = lane;
+    if (bad_l) pos = S.pr[rank_l];
+    if (bad_r) pos = S.pl[rank_r];
+    const bool rotate = o.rotate != 0;
+    if (in_range) {
+      const uint32_t r0 = pos - rel0;
+      pos = rel0 + (rotate ? (r0 >= L ? r0 - L : r0 + R) : r0);
+    }
+    // the triangles move to their new lanes
+    S.tri[pos][0] = t;
+    for (int c = 0; c < 3; c++) {
+      S.tri[pos][1 + c] = __float_as_uint(mn[c]);
+      S.tri[pos][4 + c] = __float_as_uint(mx[c]);
+      S.tri[pos][7 + c] = __float_as_uint(ce[c]);
+    }
+    __syncthreads();
+    t = S.tri[lane][0];
+    for (int c = 0; c < 3; c++) {
+      mn[c] = __uint_as_float(S.tri[lane][1 + c]);
+      mx[c] = __uint_as_float(S.tri[lane][4 + c]);
+      ce[c] = __uint_as_float(S.tri[lane][7 + c]);
+    }
+    // children: after a rotation the former right part is the first child
+    const uint32_t l_count = rotate ? R : L;
+    const float* fbox = rotate ? o.rbox : o.lbox;
+    const float* sbox = rotate ? o.lbox : o.rbox;
+    const uint32_t cid = id_base + next_local;
+    next_local += 2u;
+    if (lane == 0u) {
+      BNode& l = B.nodes[cid];
+      BNode& r = B.nodes[cid + 1u];
+      l.first = first + rel0;
+      l.count = l_count;
+      r.first = first + rel0 + l_count;
+      r.count = cnt - l_count;
+      for (int c = 0; c < 3; c++) {
+        l.mn[c] = fbox[c];
+        l.mx[c] = fbox[c + 3];
+        r.mn[c] = sbox[c];
+        r.mx[c] = sbox[c + 3];
+      }
+      l.left = l.right = r.left = r.right = -1;
+      l.leftdepth = ld + 1u;
+      r.leftdepth = ld;
+      l.gen = r.gen = B.gen;
+      B.nodes[nid].left = (int32_t)cid;
+      B.nodes[nid].right = (int32_t)(cid + 1u);
+      S.stack[sp][0] = rel0 | (l_count << 8);
+      S.stack[sp][1] = cid;
+      S.stack[sp][2] = ld + 1u;
+      S.stack[sp + 1u][0] = (rel0 + l_count) | ((cnt - l_count) << 8);
+      S.stack[sp + 1u][1] = cid + 1u;
+      S.stack[sp + 1u][2] = ld;
+      for (int c = 0; c < 6; c++) {
+        S.stack[sp][3 + c] = __float_as_uint(fbox[c]);
+        S.stack[sp + 1u][3 + c] = __float_as_uint(sbox[c]);
+      }
+    }
+    sp += 2u;
+    __syncthreads();
+  }
 }
 
 // One tree level: workgroup b takes nodes b, b + gridDim.x, ... of the level (IDS: of the level's small-node list, made by
@@ -309,6 +487,13 @@ __global__ __launch_bounds__(T) void k_level(Build B, uint32_t level) {
     const uint32_t id = IDS ? B.small_ids[blk] : id0 + blk;
     const uint32_t first = B.nodes[id].first, count = B.nodes[id].count, end = first + count;
     if (!IDS && count > kBig && tid == 0u) atomicMax(&B.ctl->big_levels, level + 1u);
+    if constexpr (T == 64) {
+      __shared__ SubShared s_sub;
+      if (count <= kSubtree) {   // the whole subtree, now
+        k_subtree(B, s_sub, id, first, count, order_in);
+        continue;
+      }
+    }
 
     // ---- 1. box of the range: the root reduces its triangles' boxes, every other node got its box from its parent's sweep
     if (id == 0u) {
@@ -840,11 +1025,13 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
 // The node array the traversal reads: {min, skip} {max, data}, skip = index after the subtree (BLAS-local).  Written at
 // out + 2 * node_base[0] (node_base == NULL: at out); a leaf's `first` is made an index into the world's topology rows
 // the way rebuilder.rs:123-134 does it: ((data >> 3) + topo_start) << 3 | (data & 7).
-__global__ __launch_bounds__(256) void k_emit(const BNode* __restrict__ nodes, const Ctl* __restrict__ ctl, const uint32_t* __restrict__ lb,
-                                              const uint32_t* __restrict__ node_base, uint32_t topo_start, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_emit(const BNode* __restrict__ nodes, uint32_t n_ids, uint32_t gen, const Ctl* __restrict__ ctl,
+                                              const uint32_t* __restrict__ lb, const uint32_t* __restrict__ node_base, uint32_t topo_start,
+                                              float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= ctl->n_nodes) return;
+  if (i >= n_ids) return;
   const BNode nd = nodes[i];
+  if (nd.gen != gen) return;   // not a node of this build
   const uint32_t l0 = lb[nd.first], l1 = lb[nd.first + nd.count];
   const uint32_t pre = 2u * l0 + nd.leftdepth, size = 2u * (l1 - l0) - 1u;
   const uint32_t skip = pre + size;

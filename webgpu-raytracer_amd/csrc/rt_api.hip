@@ -60,7 +60,7 @@ struct rt_ctx {
 
   // scene buffers (raw bridge layout)
   DeviceBuffer topology, instances, lights, draw_commands, pos, nrm, uv, nodes, textures, tex_staging;
-  uint32_t bv_levels = 0, bv_big_levels = 0, bv_last_tris = 0;   // depth of the last rt_build_blas tree: how many levels the next build launches
+  uint32_t bv_levels = 0, bv_big_levels = 0, bv_last_tris = 0, bv_gen = 0;   // depth of the last rt_build_blas tree: how many levels the next build launches
   void* bv_pinned = nullptr;  // 64 KB of pinned host memory for the read-back of the build's bookkeeping
   DeviceBuffer bv_in, bv_tri, bv_order, bv_nodes, bv_out, bv_counters, bv_big;  // BLAS build work space
   // device-resident World::update(t) (rt_world_update, csrc/world_update.hip.h)
@@ -734,7 +734,10 @@ static int blas_workspace(rt_ctx* c, uint32_t n_tris, bvhb::Build& B, bvhb::BigN
   if ((r = ensure_buffer(c, c->bv_tri, n * 48, false)) < 0) return r;
   // ord[0], ord[1], order_final, scratch_l, scratch_r, leaf_flag, small_ids, lb (n + 1), block counts; bin cache (bytes)
   if ((r = ensure_buffer(c, c->bv_order, (8 * n + 4 + n_blk) * 4 + n + 16, false)) < 0) return r;
-  if ((r = ensure_buffer(c, c->bv_nodes, max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
+  // node records: ids [0, 2n) of the level kernels, [2n, 4n) blocks of the in-wave subtrees; a fresh array is zeroed once
+  // (records carry the stamp of the build that made them, stamps start at 1)
+  if ((r = ensure_buffer(c, c->bv_nodes, 2 * max_nodes * sizeof(bvhb::BNode), false)) < 0) return r;
+  if (r > 0) HIP_TRY(c, hipMemsetAsync(c->bv_nodes.ptr, 0, c->bv_nodes.capacity, c->stream));
   if ((r = ensure_buffer(c, c->bv_counters, sizeof(bvhb::Ctl), false)) < 0) return r;
   const uint32_t nb = bvhb::big_cap(n_tris), nc = bvhb::chunk_cap(n_tris);
   if ((r = ensure_buffer(c, c->bv_big, (size_t)nb * sizeof(bvhb::BigNode) + (size_t)nc * (sizeof(bvhb::Chunk) + 16), false)) < 0) return r;
@@ -755,6 +758,12 @@ static int blas_workspace(rt_ctx* c, uint32_t n_tris, bvhb::Build& B, bvhb::BigN
   B.bin_cache = (uint8_t*)(d_blk + n_blk);
   B.nodes = (bvhb::BNode*)c->bv_nodes.ptr;
   B.ctl = (bvhb::Ctl*)c->bv_counters.ptr;
+  B.n_tris = n_tris;
+  B.gen = ++c->bv_gen;
+  if (B.gen == 0u) {   // stamp wrap-around: forget every old record
+    HIP_TRY(c, hipMemsetAsync(c->bv_nodes.ptr, 0, c->bv_nodes.capacity, c->stream));
+    B.gen = c->bv_gen = 1u;
+  }
   d_big = (bvhb::BigNode*)c->bv_big.ptr;
   d_chunks = (bvhb::Chunk*)(d_big + nb);
   d_cnt = (uint32_t*)(d_chunks + nc);
@@ -814,8 +823,8 @@ static int blas_enqueue(rt_ctx* c, const float4* d_pos, const uint32_t* d_idx, u
   hipLaunchKernelGGL(bvhb::k_scan_top, dim3(1), dim3(1024), 0, c->stream, d_blk, n_blk, B.ctl, node_base);
   hipLaunchKernelGGL(bvhb::k_scan_apply, dim3(n_blk), dim3(1024), 0, c->stream, (const uint32_t*)B.leaf_flag, n_tris, (const uint32_t*)d_blk,
                      (const bvhb::Ctl*)B.ctl, d_lb);
-  hipLaunchKernelGGL(bvhb::k_emit, dim3((2 * n_tris + 255) / 256), dim3(256), 0, c->stream, (const bvhb::BNode*)B.nodes, (const bvhb::Ctl*)B.ctl,
-                     (const uint32_t*)d_lb, (const uint32_t*)node_base, topo_start, out);
+  hipLaunchKernelGGL(bvhb::k_emit, dim3((4 * n_tris + 255) / 256), dim3(256), 0, c->stream, (const bvhb::BNode*)B.nodes, 4u * n_tris, B.gen,
+                     (const bvhb::Ctl*)B.ctl, (const uint32_t*)d_lb, (const uint32_t*)node_base, topo_start, out);
   HIP_TRY(c, hipGetLastError());
   return RT_OK;
 }
@@ -1226,6 +1235,9 @@ int rt_world_read(rt_ctx* c, int which, void* out, size_t cap_bytes, size_t* byt
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RT_OK;
 }
+
+// depth of the last rt_build_blas tree (levels of the breadth-first build that held nodes) | large-node levels << 16
+int rt_build_blas_levels(const rt_ctx* c) { return c ? (int)(c->bv_levels | (c->bv_big_levels << 16)) : 0; }
 
 int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
   if (!c) return RT_ERR_INVALID;
