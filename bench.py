@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the lines of BASELINE configs 3-5")
     ap.add_argument("--no-live-loop", action="store_true", help="skip the per-frame compute(); present() block")
+    ap.add_argument("--no-world-update", action="store_true", help="skip the World::update(t) block (host / GPU builder / device-resident)")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per batched dispatch (the recorder batches up to 50 compute() calls; 1 = one dispatch per frame)")
     return ap.parse_args()
@@ -338,6 +339,51 @@ def main():
                 "lookahead": lookahead,
                 "ms_per_frame": round(dt / (passes * nframes) * 1e3, 4), "Mrays_s": round(rays / dt / 1e6, 1), "frames": passes * nframes}
 
+    def world_update_block(scene="sponza_like", width=WIDTH, height=HEIGHT):
+        """World::update(t) + the scene sync of the live loop (src/main.ts:133-163) on config 4's scene, three ways: the
+        scene compiler on the host (the reference's way: lib.rs:149-270, one CPU thread for the BLAS), the host path
+        with the GPU BLAS builder as its hook (round 2), and the device-resident update (rt_world_update: skinning,
+        BLAS, topology / lights / draw commands, TLAS and instances on the GPU, nothing uploaded).  ms per update."""
+        r = pkg.WebGPURenderer(local_rank)
+        r.buildPipeline(DEPTH, 1)
+        res = {"scene": scene}
+        for mode, reps in (("host_cpu_builder", 2), ("host_gpu_blas_hook", 5), ("device_resident", 20)):
+            b = pkg.WorldBridge(zero_copy=True)
+            if mode == "host_gpu_blas_hook":
+                b.setBlasBuilder(r)
+            elif mode == "device_resident":
+                b.setDeviceUpdater(r)
+            b.loadScene(scene)
+            pkg.upload_scene(r, b, width, height)
+            res["triangles"] = len(b.mesh_topology) // 20
+            for _ in range(3 if mode != "host_cpu_builder" else 1):
+                b.update(0.0)
+                pkg.sync_world(r, b, width, height)
+            r.sync()
+            t_upd = t_sync = t_gpu = 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                b.update(0.0)
+                t1 = time.perf_counter()
+                pkg.sync_world(r, b, width, height)
+                r.sync()
+                t2 = time.perf_counter()
+                t_upd += t1 - t0
+                t_sync += t2 - t1
+                if mode == "device_resident":
+                    if not b.deviceResident:
+                        raise SystemExit("bench.py: the device-resident update fell back to the host: " + b.deviceWarning)
+                    t_gpu += r.worldLastMs()
+            e = {"update_ms": round(t_upd / reps * 1e3, 3), "upload_ms": round(t_sync / reps * 1e3, 3)}
+            if mode == "device_resident":
+                e["gpu_stream_ms"] = round(t_gpu / reps, 3)
+            res[mode] = e
+            b.close()
+        r.destroy()
+        res["device_over_host"] = round((res["host_cpu_builder"]["update_ms"] + res["host_cpu_builder"]["upload_ms"]) /
+                                        (res["device_resident"]["update_ms"] + res["device_resident"]["upload_ms"]), 1)
+        return res
+
     frames = list(range(1, SPP_TOTAL + 1))
     head = run_workload(SCENE, frames, DEPTH, args.steps, args.warmup, args.batch)
     extra = []
@@ -502,6 +548,8 @@ def main():
                         e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
                     ll.append(e)
             out["live_loop"] = ll
+        if world == 1 and not args.no_world_update:
+            out["world_update"] = world_update_block()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, head["bridge"], frames)
         print(json.dumps(out), flush=True)

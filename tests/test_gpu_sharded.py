@@ -129,7 +129,7 @@ def test_bench_py_gpus_2_from_a_plain_shell(W):
     if renderer.load_library().rt_device_count() < 2:
         env.update(BENCH_ONE_DEVICE="1", BENCH_BACKEND="gloo")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop", "--no-world-update"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -137,7 +137,7 @@ def test_bench_py_gpus_2_from_a_plain_shell(W):
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["unit"] == "Mrays/s" and rec["value"] > 0
     # every ray of the image is traced exactly once across the ranks: same count as one GPU (deterministic)
     one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extra-configs", "--no-cpu-baseline", "--no-live-loop", "--no-world-update"], env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert rec1["config"]["rays_per_image"] == rec["config"]["rays_per_image"]

@@ -137,9 +137,11 @@ def test_javascript_bridge_loads_a_glb_like_the_python_bridge(W, addon, tmp_path
 
 @needs_node
 @pytest.mark.gpu
-def test_javascript_live_loop_on_an_animated_glb_matches_the_oracle(W, oracle_lib, addon, tmp_path):
-    """node/animate_glb.js: LiveLoop (main.ts renderFrame) over a skinned, animated, textured GLB with the GPU BLAS builder,
-    against the oracle driven by the Python LiveLoop on the same frames."""
+@pytest.mark.parametrize("mode", ["RT_NODE_GPU_BLAS", "RT_NODE_DEVICE_UPDATE"])
+def test_javascript_live_loop_on_an_animated_glb_matches_the_oracle(W, oracle_lib, addon, tmp_path, mode):
+    """node/animate_glb.js: LiveLoop (main.ts renderFrame) over a skinned, animated, textured GLB with the GPU BLAS builder
+    or with the whole update(t) on the device (rt_world_update), against the oracle driven by the Python LiveLoop on the
+    same frames."""
     import test_gltf
     b, _ = test_gltf.build_skinned(W)
     b.image_texture(W.textures.encode_png(np.full((4, 4, 4), 180, np.uint8)))
@@ -147,10 +149,11 @@ def test_javascript_live_loop_on_an_animated_glb_matches_the_oracle(W, oracle_li
     b.doc["meshes"][0]["primitives"][0]["material"] = 0
     path = tmp_path / "strip.glb"
     path.write_bytes(b.glb())
-    env = dict(os.environ, RT_NODE_GPU_BLAS="1")
+    env = dict(os.environ, **{mode: "1"})
     out = subprocess.run([node, os.path.join(NODE_DIR, "animate_glb.js"), str(path), "96", "64", "7", "2", "5"],
                          check=True, capture_output=True, text=True, timeout=600, env=env).stdout
     got = json.loads(out.strip().splitlines()[-1])
+    assert got["deviceResident"] == (mode == "RT_NODE_DEVICE_UPDATE")
     br = W.WorldBridge()
     br.loadScene("viewer", glbData=b.glb())
     cpu = oracle_lib.OracleRenderer()

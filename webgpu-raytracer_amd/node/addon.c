@@ -383,6 +383,22 @@ static napi_value msSetBlasBuilder(napi_env env, napi_callback_info info) {
   ms_world_set_blas_builder((ms_world*)get_ptr(env, a[0]), ctx ? (ms_blas_builder)rt_build_blas : NULL, ctx);
   return NULL;
 }
+/* (world, ctx | null): the whole per-frame half of World::update(t) runs on the GPU inside the renderer's buffers
+ * (rt_world_update); the host arrays are then not refreshed and nothing needs uploading */
+static napi_value msSetDeviceUpdater(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  napi_valuetype vt;
+  napi_typeof(env, a[1], &vt);
+  void* ctx = vt == napi_external ? get_ptr(env, a[1]) : NULL;
+  ms_world_set_device_updater((ms_world*)get_ptr(env, a[0]), ctx ? (ms_device_updater)rt_world_update : NULL, ctx);
+  return NULL;
+}
+static napi_value msDeviceResident(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  return make_int(env, ms_world_device_resident((const ms_world*)get_ptr(env, a[0])));
+}
 static napi_value msLastError(napi_env env, napi_callback_info info) {
   napi_value s;
   (void)info;
@@ -442,7 +458,8 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"msUpdate", msUpdate}, {"msUpdateCamera", msUpdateCamera}, {"msGet", msGet},
                {"msTextureCount", msTextureCount}, {"msTexture", msTexture},
                {"msAnimationNames", msAnimationNames}, {"msSetAnimation", msSetAnimation},
-               {"msLoadAnimation", msLoadAnimation}, {"msLastError", msLastError}, {"msSetBlasBuilder", msSetBlasBuilder},
+               {"msLoadAnimation", msLoadAnimation}, {"msLastError", msLastError}, {"msSetBlasBuilder", msSetBlasBuilder}, {"msSetDeviceUpdater", msSetDeviceUpdater},
+               {"msDeviceResident", msDeviceResident},
                {"msEncodedTextureCount", msEncodedTextureCount}, {"msEncodedTexture", msEncodedTexture}};
   for (size_t i = 0; i < sizeof(table) / sizeof(table[0]); i++) {
     napi_value fn;

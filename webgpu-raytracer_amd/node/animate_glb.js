@@ -15,6 +15,7 @@ const { WebGPURenderer, WorldBridge, LiveLoop } = require('./index.js');
   const bridge = new WorldBridge();
   await bridge.initWasm();
   if (process.env.RT_NODE_GPU_BLAS) bridge.setBlasBuilder(renderer);
+  if (process.env.RT_NODE_DEVICE_UPDATE) bridge.setDeviceUpdater(renderer);   // update(t) inside the renderer (rt_world_update)
   await bridge.loadScene('viewer', undefined, new Uint8Array(fs.readFileSync(file)));
   await renderer.loadTexturesFromWorld(bridge);
   renderer.updateScreenSize(width, height);
@@ -25,6 +26,6 @@ const { WebGPURenderer, WorldBridge, LiveLoop } = require('./index.js');
   const frame = await renderer.captureFrame();
   const sha = (buf) => crypto.createHash('sha256').update(Buffer.from(buf)).digest('hex');
   console.log(JSON.stringify({ frames: parseInt(frames, 10), animations: bridge.getAnimationList(), frameCount: loop.frameCount,
-    accum_sha256: sha(acc.buffer), rgba_sha256: sha(frame.data) }));
+    accum_sha256: sha(acc.buffer), rgba_sha256: sha(frame.data), deviceResident: !!bridge.deviceResident }));
   renderer.destroy();
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -44,6 +44,10 @@ export class WorldBridge {
   getTextureRGBA(index: number): Uint8Array | undefined;
   /** build the BLASes of update(t) on the GPU with this renderer (same tree as the CPU builder); null restores the CPU builder */
   setBlasBuilder(renderer: WebGPURenderer | null): void;
+  /** the whole per-frame half of update(t) on the GPU (rt_world_update); the host arrays are then not refreshed */
+  setDeviceUpdater(renderer: WebGPURenderer | null): void;
+  deviceResident: boolean;
+  deviceWarning: string;
   getAnimationList(): string[];
   loadAnimation(data: Uint8Array): number;
   setAnimation(index: number): void;

@@ -137,6 +137,8 @@ class WorldBridge {
     // a GLB that does not parse leaves the procedural scene alone (lib.rs:57-67 ignores the error); keep the reason
     this.loadWarning = glbData ? native.msLastError() : '';
     if (this._blasRenderer) native.msSetBlasBuilder(this._w, this._blasRenderer._ctx);
+    if (this._deviceRenderer) native.msSetDeviceUpdater(this._w, this._deviceRenderer._ctx);
+    this.deviceResident = false;
     this._wh = [-1, -1];
     this._refresh();
     this.hasNewData = true;
@@ -144,12 +146,23 @@ class WorldBridge {
   }
   update(time) {
     if (this._blasRenderer && !this._blasRenderer._ctx) throw new Error('the renderer set with setBlasBuilder() has been destroyed');
+    if (this._deviceRenderer && !this._deviceRenderer._ctx) throw new Error('the renderer set with setDeviceUpdater() has been destroyed');
     native.msUpdate(this._w, time);
-    if (this._blasRenderer) {
+    this.deviceResident = !!native.msDeviceResident(this._w);
+    this.deviceWarning = (this._deviceRenderer && !this.deviceResident) ? native.msLastError() : '';
+    if (!this._deviceRenderer && this._blasRenderer) {
       const err = native.msLastError();
       if (err) throw new Error(err);   // the GPU builder failed: no silent CPU result
     }
-    this._refresh(); this.hasNewData = true; this.hasNewGeometry = true;
+    if (!this.deviceResident) this._refresh();   // a device-resident update leaves the host arrays alone
+    this.hasNewData = true; this.hasNewGeometry = true;
+  }
+  // run the whole per-frame half of update(t) on the GPU, inside `renderer`'s buffers (rt_world_update): skinning, BLAS
+  // builds, topology / light / draw-command packing, TLAS, instances; syncWorld() then uploads nothing.  null = host path
+  setDeviceUpdater(renderer) {
+    this._deviceRenderer = renderer || null;
+    if (this._w) native.msSetDeviceUpdater(this._w, renderer ? renderer._ctx : null);
+    if (!renderer) this.deviceResident = false;
   }
   // build the BLASes of update(t) on the GPU (rt_build_blas: the CPU builder's tree, byte for byte); null = CPU builder
   setBlasBuilder(renderer) {
@@ -199,6 +212,14 @@ class WorldBridge {
 function syncWorld(renderer, bridge, width, height) {
   if (!bridge.hasNewData) return false;
   let rebind = false;
+  if (bridge.deviceResident) {   // update(t) ran inside the renderer: only the camera uniforms and the restart remain
+    bridge.hasNewGeometry = false;
+    bridge.updateCamera(width, height);
+    renderer.updateSceneUniforms(bridge.cameraData, 0, bridge.lightCount);
+    renderer.resetAccumulation();
+    bridge.hasNewData = false;
+    return true;
+  }
   rebind = renderer.updateCombinedBVH(bridge.tlas, bridge.blas) || rebind;
   rebind = renderer.updateBuffer('instance', bridge.instances) || rebind;
   rebind = renderer.updateBuffer('draw_commands', bridge.draw_commands) || rebind;
