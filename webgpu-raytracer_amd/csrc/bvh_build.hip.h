@@ -38,8 +38,14 @@
 namespace bvhb {
 
 constexpr int kBins = 16;
-constexpr uint32_t kBig = 4096u;    // nodes above this many triangles are worked on by many workgroups (k_big_*)
-constexpr uint32_t kChunk = 2048u;  // ... in chunks of this many positions
+#ifndef RT_BLAS_BIG
+#define RT_BLAS_BIG 4096u
+#endif
+#ifndef RT_BLAS_CHUNK
+#define RT_BLAS_CHUNK 2048u
+#endif
+constexpr uint32_t kBig = RT_BLAS_BIG;      // nodes above this many triangles are worked on by many workgroups (k_big_*)
+constexpr uint32_t kChunk = RT_BLAS_CHUNK;  // ... in chunks of this many positions
 
 constexpr uint32_t kMaxLevels = 1024;  // deeper trees are refused (Ctl::cnt has one word per level)
 

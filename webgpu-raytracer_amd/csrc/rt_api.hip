@@ -89,6 +89,7 @@ struct rt_ctx {
                                     // node array or the SET of BLAS roots changed
   std::vector<float> root_w_host;                                   // per entry of blas_roots: sum of squared instance scales
   bool tris_dirty = true, inst_dirty = true, lights_dirty = true, nodes_dirty = true, pairs_dirty = true;
+  bool pairs_wanted = false;        // rt_debug_read_pairs: build the pair records whatever walk is selected
   int wf_block = 0;              // threads per workgroup of the wavefront trace kernels (0 = default; MI355RT_WF_BLOCK)
   size_t lds_per_cu = 160 * 1024;
   bool validate_dirty = true, scene_valid = false;  // k_validate_scene: run once per upload
@@ -384,7 +385,10 @@ int prepare_scene(rt_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     c->nodes_dirty = false;
   }
-  if ((c->pairs_dirty || c->roots_dirty) && c->n_nodes && c->n_instances) {
+  // the pair records are only walked by the wavefront trace kernels under the pair walk (rt_set_walk): a scene that takes
+  // the node walk does not pay for them on every update(t); they are made when a launch (or rt_debug_read_pairs) wants them
+  const bool want_pairs = c->pairs_wanted || c->walk == 1 || (c->walk == 2 && c->n_instances == 1);
+  if (want_pairs && (c->pairs_dirty || c->roots_dirty) && c->n_nodes && c->n_instances) {
     // child-pair records of the walk (k_pairs.hip.h); validate_scene has uploaded the sorted BLAS roots into val_roots and
     // vouches for every pointer followed here.  An instance upload that keeps the set of BLAS roots only redoes the root
     // records (one small launch) — what an animated scene pays per update(t).
@@ -888,6 +892,8 @@ static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
   if (!f->n_instances || !f->instances || (f->n_geometries && !f->geometries))
     return fail(c, RT_ERR_INVALID, "rt_world_update: empty scene description");
   const uint32_t G = f->n_geometries, N = f->n_instances;
+  if (N > 16384u)   // k_tlas sorts by rank counting, N^2 / 1024 comparisons per lane: fine for thousands, not for more
+    return fail(c, RT_ERR_INVALID, "rt_world_update: more than 16 384 instances are not taken by the device path");
   // layout of the static buffer (256-byte aligned arrays) and the world's totals
   size_t bytes = 0;
   auto take = [&](size_t n) { size_t o = bytes; bytes += (n + 255) & ~(size_t)255; return o; };
@@ -2115,7 +2121,9 @@ int rt_debug_read_traversal_nodes(rt_ctx* c, float* tnodes_out, uint32_t* new_in
 int rt_debug_read_pairs(rt_ctx* c, float* pairs_out, float* root_rec_out, uint32_t cap_pairs) {
   if (!c) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
+  c->pairs_wanted = true;
   int r = prepare_scene(c);
+  c->pairs_wanted = false;
   if (r < 0) return r;
   if (cap_pairs < c->n_pairs || !c->pairs.ptr || !c->root_rec.ptr) return fail(c, RT_ERR_INVALID, "rt_debug_read_pairs: no records or buffer too small");
   if (pairs_out && c->n_pairs) HIP_TRY(c, hipMemcpyAsync(pairs_out, c->pairs.ptr, (size_t)c->n_pairs * 64, hipMemcpyDeviceToHost, c->stream));
