@@ -547,6 +547,13 @@ def main():
                         e["batched_ms_per_frame"] = round(batched[scene], 4)
                         e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
                     ll.append(e)
+                # the same with a still view four times as long: the ramp and the (at most 31) frames traced in vain when the
+                # run ends are a fixed cost per run, so the ratio depends on how long the camera rests
+                e = live_loop(scene, 1024, depth, lookahead=32, passes=1)
+                if scene in batched:
+                    e["batched_ms_per_frame"] = round(batched[scene], 4)
+                    e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
+                ll.append(e)
             out["live_loop"] = ll
         if world == 1 and not args.no_world_update:
             out["world_update"] = world_update_block()

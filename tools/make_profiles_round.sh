@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence of a round (run on the GPU box via gpurun; HEAD=<commit> in the environment names the code state,
 # RTAG=<rNN> the file prefix under profiles/).  One counter set per run (never --pmc together with other trace domains).
-# usage: RTAG=r03 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|big|glass|calib|scene <name>|all]
+# usage: RTAG=r03 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|big|glass|world|calib|scene <name>|all]
 R=$GRAFT_REPO_ROOT
 WHAT=${1:-all}
 RTAG=${RTAG:-r03}
@@ -27,6 +27,13 @@ if [ "$WHAT" = cornell ] || [ "$WHAT" = all ]; then
   pmc_pass write cornell 64 8 32 2 WRITE_SIZE
   pmc_pass grbm cornell 64 8 32 2 GRBM_GUI_ACTIVE
   python3 $R/tools/pmc_collect.py $OUT/pmc_cornell $OUT/${RTAG}_cornell_pmc.json > /dev/null
+fi
+if [ "$WHAT" = world ] || [ "$WHAT" = all ]; then
+  # the device-resident update(t) (rt_world_update) inside the animated live loop: per-kernel durations of 43 displayed frames
+  MODES=device timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_world -- python3 $R/tools/animate_bench.py 512 256 40 > $OUT/${RTAG}_world_update.log 2>&1
+  cp $OUT/trace_world/*/*_kernel_stats.csv $OUT/${RTAG}_world_update_kernel_stats.csv
+  rm -rf $OUT/trace_world
+  timeout -k 10 300 python3 $R/tools/animate_bench.py 512 256 40 2>&1 | grep "triangles skinned" > $OUT/${RTAG}_animate_bench.txt
 fi
 if [ "$WHAT" = scene ]; then SCENES="$2"; fi
 if [ "$WHAT" = big ] || [ "$WHAT" = all ] || [ "$WHAT" = scene ]; then
@@ -67,6 +74,7 @@ if [ "$WHAT" = glass ] || [ "$WHAT" = all ]; then
   unset MI355RT_WF_OVERLAP
 fi
 if [ "$WHAT" = scene ]; then ls $OUT; exit 0; fi
+if [ "$WHAT" = world ]; then ls $OUT; exit 0; fi
 if [ "$WHAT" != calib ] && [ "$WHAT" != all ]; then
   python3 $R/tools/pmc_reference.py $OUT ${HEAD:-unknown} $OUT/pmc_reference.json > /dev/null
   ls $OUT
