@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence of a round (run on the GPU box via gpurun; HEAD=<commit> in the environment names the code state,
 # RTAG=<rNN> the file prefix under profiles/).  One counter set per run (never --pmc together with other trace domains).
-# usage: RTAG=r03 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|big|glass|world|calib|scene <name>|all]
+# usage: RTAG=r03 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|bench|big|glass|world|calib|scene <name>|all]
 R=$GRAFT_REPO_ROOT
 WHAT=${1:-all}
 RTAG=${RTAG:-r03}
@@ -13,12 +13,14 @@ pmc_pass() {  # name scene frames depth batch images counters...
   local name=$1 scene=$2 frames=$3 depth=$4 batch=$5 images=$6; shift 6
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$scene/$name -- python3 $R/tools/prof_workload.py $scene $frames $depth $batch $images > $OUT/pmc_${scene}_$name.log 2>&1 || { echo "pass failed: $scene $name"; tail -3 $OUT/pmc_${scene}_$name.log; }
 }
-if [ "$WHAT" = cornell ] || [ "$WHAT" = all ]; then
-  # 1. kernel trace + stats of the bench command itself
+if [ "$WHAT" = cornell ] || [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+  # 1. kernel trace + stats of the bench command itself (mode `bench`: only this, after profiles/pmc_reference.json of the
+  #    same kernel sources is in place, so that the line carries the counters)
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-world-update > $OUT/${RTAG}_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
   grep -c '"metric"' $OUT/${RTAG}_bench_under_rocprof.json || tail -5 $OUT/bench_under_rocprof.err
   cp $OUT/bench_trace/*/*_kernel_stats.csv $OUT/${RTAG}_bench_kernel_stats.csv
   rm -rf $OUT/bench_trace
+  if [ "$WHAT" = bench ]; then ls $OUT; exit 0; fi
   # 2. PMC passes, each in its own run: 2 images = 4 path-trace launches of 32 frames
   rm -rf $OUT/pmc_cornell
   pmc_pass sq1 cornell 64 8 32 2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
