@@ -153,6 +153,9 @@ __device__ __forceinline__ bool pw_busy(const PairLane& s) { return s.state != P
                                 // the way out of an instance, is followed by the next entry at once — swept 1 / 2 / 3 on MI355X,
                                 // ms per 32-frame batch of the 263 k-triangle hall: 184.7 / 187.0 / 189.6)
 #endif
+#ifndef RT_PW_POP_FIRST
+#define RT_PW_POP_FIRST 1       // 1: pops before the round's record request (pw_trip), 0: behind it
+#endif
 
 // STEPS record fetches for every lane that wants one, with the cheap transitions (pop, enter an instance) in between.
 // LDS = every record is in LDS (plain ds_read, entry on the spot).  wave_lds: this wave's LDS block (the fetch regions lie
@@ -186,14 +189,11 @@ __device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, f4* wav
   const f4* mine = wave_lds + (lane & 3u) * RT_PW_REGION_SLOTS + (lane >> 2) * 4u;
 #pragma unroll
   for (int k = 0; k < STEPS; k++) {
-    // ---- the lanes that know their next record ask for it first (global memory: the LDS-DMA loads are in flight while
-    //      the other lanes pop / enter below; those lanes fetch in the next round)
-    bool need = s.state == PW_FETCH || s.state == PW_FETCHR;
-    unsigned long long need_mask = __ballot(need);
-    if (!LDS && need_mask != 0ull) pw_fetch_dma(M.gpairs, wave_lds, need_mask, s.curr);
-#ifdef RT_PW_STAMPS
-    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[0] += t_ - pw_t; pw_t = t_; pw_cyc[5]++; }   // no wait here: the loads stay in flight
-#endif
+    // ---- pops first (RT_PW_POP_FIRST, default): a lane whose two children both missed in the last round takes its next
+    //      record off its stack BEFORE the records are asked for, so it tests a pair in EVERY round; with the pops behind the
+    //      request (0: they overlap the loads' flight) such a lane tested a pair every second round — half the lanes of
+    //      the slab tests idle (rocprof: 32 of 64 lanes per vector instruction)
+#if RT_PW_POP_FIRST
     // ---- transitions that need no record
 #pragma unroll
     for (int rep = 0; rep < RT_PW_POP_REPS; rep++) {
@@ -203,6 +203,27 @@ __device__ __forceinline__ void pw_trip(const PairMem& M, const f4* lds, f4* wav
     }
 #ifdef RT_PW_STAMPS
     { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[1] += t_ - pw_t; pw_t = t_; }
+#endif
+#endif
+    // ---- the lanes that know their next record ask for it first (global memory: the LDS-DMA loads are in flight while
+    //      the other lanes pop / enter below; those lanes fetch in the next round)
+    bool need = s.state == PW_FETCH || s.state == PW_FETCHR;
+    unsigned long long need_mask = __ballot(need);
+    if (!LDS && need_mask != 0ull) pw_fetch_dma(M.gpairs, wave_lds, need_mask, s.curr);
+#ifdef RT_PW_STAMPS
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[0] += t_ - pw_t; pw_t = t_; pw_cyc[5]++; }   // no wait here: the loads stay in flight
+#endif
+#if !RT_PW_POP_FIRST
+    // ---- transitions that need no record
+#pragma unroll
+    for (int rep = 0; rep < RT_PW_POP_REPS; rep++) {
+      if (__ballot(s.state == PW_POP) != 0ull) {
+        if (s.state == PW_POP) pw_pop<COUNT>(s, stk, n_nodes);
+      }
+    }
+#ifdef RT_PW_STAMPS
+    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw_cyc[1] += t_ - pw_t; pw_t = t_; }
+#endif
 #endif
     // ---- instance entry: on the spot when the rows are in LDS; else when enough lanes wait, or nobody else can move
     {
