@@ -184,6 +184,10 @@ int rt_kernel_time_ms(rt_ctx* ctx, double* avg_pathtrace_ms, double* avg_primary
  * ...) drops what was traced ahead.  While it is on, the ray counters count a frame when it is TRACED (ahead of its compute()
  * call), and the detailed-counter build does not trace ahead.  0 (default) / 1 = off. */
 int rt_set_lookahead(rt_ctx* ctx, uint32_t max_frames);
+/* A caller that knows when its run of consecutive frames ends - renderFrame advances the world every updateInterval frames
+ * (main.ts:127-131) - says so: the next rt_compute traces at most `frames_left` frames (itself included), so nothing is
+ * traced ahead in vain across the end of the run.  0 = unknown (the default).  Changes no result and discards nothing. */
+int rt_set_lookahead_limit(rt_ctx* ctx, uint32_t frames_left);
 /* Traversal of the wavefront trace kernels: 1 = child-pair records (csrc/k_pairwalk.hip.h: one 64-byte record per inner
  * node, both children tested per fetch, quad-cooperative LDS-DMA fetch, short per-lane stack); 0 = one 32-byte node per step
  * with skip pointers only (rounds 1-2); 2 (default) = auto: pairs for a scene of one instance, nodes otherwise (where each

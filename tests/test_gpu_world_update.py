@@ -80,6 +80,34 @@ def test_frames_from_the_device_world_equal_frames_from_uploaded_arrays(W):
 
 
 @pytest.mark.gpu
+def test_animated_live_loop_traces_nothing_in_vain(W):
+    """A world that moves every 4th frame, lookahead on: the loop tells the library when the run ends
+    (rt_set_lookahead_limit), so the images are those of one dispatch per frame AND exactly the displayed frames were
+    traced (with lookahead the ray counters count a frame when it is traced)."""
+    glb = test_gltf.big_skinned_glb(W, 48, 24)[0]
+    out = []
+    for look in (0, 32):
+        r = W.WebGPURenderer(0)
+        r.buildPipeline(4, 1)
+        b = W.WorldBridge(zero_copy=True)
+        b.setDeviceUpdater(r)
+        b.loadScene("viewer", glbData=glb)
+        W.upload_scene(r, b, 256, 144)
+        loop = W.LiveLoop(r, b, 256, 144, update_interval=4, lookahead=look)
+        r.resetCounters()
+        imgs = []
+        for _ in range(16):                      # four whole runs of four frames
+            loop.render_frame()
+            imgs.append(r.readAccum().copy())
+        out.append((imgs, r.getCounters()))
+        r.destroy()
+    for k, (a, d) in enumerate(zip(out[0][0], out[1][0])):
+        assert np.array_equal(a.view(np.uint32), d.view(np.uint32)), k
+    assert out[0][1]["primary_rays"] == 16 * 256 * 144
+    assert dict(out[0][1]) == dict(out[1][1]), (out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
 def test_device_updater_refuses_a_destroyed_renderer(W):
     r = W.WebGPURenderer(0)
     b = W.WorldBridge()

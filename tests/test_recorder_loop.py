@@ -92,6 +92,9 @@ def test_live_loop_follows_main_ts(W):
         loop.render_frame()
     assert rec.calls[0][0] == "setLookahead"      # the loop lets the library trace a still scene's consecutive frames ahead
     rec.calls = rec.calls[1:]
+    # ... and tells it how many frames are left until the world moves again, so that nothing is traced ahead in vain
+    assert [c[1] for c in rec.calls if c[0] == "setLookaheadLimit"] == [3, 2, 1, 3, 2, 1, 3, 2]
+    rec.calls = [c for c in rec.calls if c[0] != "setLookaheadLimit"]
     names = [c[0] for c in rec.calls]
     first_sync = ["updateCombinedBVH", "updateBuffer", "updateBuffer", "updateCombinedGeometry", "updateBuffer", "updateBuffer",
                   "updateSceneUniforms", "resetAccumulation"]

@@ -158,6 +158,7 @@ struct rt_ctx {
   uint32_t run_len = 0, run_last_fc = 0, run_last_tf = 0;   // the run of consecutive single-frame compute() calls
   uint64_t run_epoch = 0;
   uint32_t look = 1;                // frames the next dispatch of the run traces
+  uint32_t look_limit = 0;          // rt_set_lookahead_limit: frames (this one included) until the caller will end the run; 0 = unknown
   int gbuf_slot = -1;               // >= 0: the last compute() consumed this frame of the traced batch (rt_read_gbuffer)
   uint32_t acc_frames = 0;          // frames k_accumulate_frames adds at the end of a dispatch (all of them unless traced ahead)
   DeviceBuffer gbuf_batch;  // G-buffer planes of frames 0..n-2 of a batch (the last frame uses the main planes)
@@ -1898,6 +1899,7 @@ int rt_compute(rt_ctx* c, uint32_t frame_count) {
   // does this call continue a run of consecutive frames?  Then trace ahead, twice as far as last time.
   const bool continues = c->run_epoch == c->epoch && frame_count == c->run_last_fc + 1 && c->total_frames == c->run_last_tf;
   c->look = continues ? std::min<uint32_t>(std::min<uint32_t>(c->look * 2u, c->lookahead_max), 64u) : 1u;
+  if (c->look_limit) c->look = std::max<uint32_t>(1u, std::min(c->look, c->look_limit));   // rt_set_lookahead_limit: the caller knows when the run ends
   c->run_epoch = c->epoch;
   uint32_t fcs[64];
   for (uint32_t i = 0; i < c->look; i++) fcs[i] = frame_count + i;
@@ -1919,6 +1921,12 @@ int rt_set_lookahead(rt_ctx* c, uint32_t max_frames) {
   if (max_frames > 64) return fail(c, RT_ERR_INVALID, "at most 64 frames of lookahead");
   c->lookahead_max = max_frames;
   c->epoch++;
+  return RT_OK;
+}
+
+int rt_set_lookahead_limit(rt_ctx* c, uint32_t frames_left) {
+  if (!c) return RT_ERR_INVALID;
+  c->look_limit = frames_left;   // changes no result and drops nothing: only how far the next dispatches trace ahead
   return RT_OK;
 }
 

@@ -174,6 +174,7 @@ def load_library(path=None):
                                     ctypes.POINTER(u32)]),
         "rt_set_kernel_timing": (i32, [vp, i32]), "rt_device_count": (i32, []),
         "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]), "rt_set_lookahead": (i32, [vp, u32]),
+        "rt_set_lookahead_limit": (i32, [vp, u32]),
         "rt_build_blas_levels": (i32, [vp]),
         "rt_world_update": (i32, [vp, vp]), "rt_world_last_ms": (ctypes.c_double, [vp]),
         "rt_world_read": (i32, [vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
@@ -195,7 +196,7 @@ EXPORTED_SYMBOLS = (
     "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_read_traversal_nodes rt_debug_read_pairs "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead "
-    "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels").split()
+    "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit").split()
 
 
 def _ptr(a):
@@ -431,6 +432,10 @@ class WebGPURenderer:
         1 = persistent waves + path regeneration, 0 = one pixel per lane megakernel; all bit-identical"""
         self._check(self.L.rt_set_kernel_variant(self.ctx, int(variant)), "setKernelVariant")
 
+    def setLookaheadLimit(self, frames_left):
+        """the run of consecutive frames ends in `frames_left` frames (this one included): trace no further ahead; 0 = unknown"""
+        self._check(self.L.rt_set_lookahead_limit(self.ctx, int(frames_left)), "setLookaheadLimit")
+
     def setLookahead(self, max_frames):
         """speculative lookahead of the live loop (rt_set_lookahead): consecutive compute(f) calls are traced ahead as batches"""
         self._check(self.L.rt_set_lookahead(self.ctx, int(max_frames)), "setLookahead")
@@ -536,5 +541,8 @@ class LiveLoop:
             self.frameCount = 0
         self.frameCount += 1
         self.totalFrameCount += 1
+        if self.update_interval > 0 and hasattr(self.renderer, "setLookaheadLimit"):
+            # the world moves again in update_interval - frameCount + 1 frames: nothing is traced ahead past that
+            self.renderer.setLookaheadLimit(max(1, self.update_interval - self.frameCount + 1))
         self.renderer.compute(self.frameCount)
         self.renderer.present()
