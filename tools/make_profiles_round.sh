@@ -16,7 +16,7 @@ pmc_pass() {  # name scene frames depth batch images counters...
 if [ "$WHAT" = cornell ] || [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   # 1. kernel trace + stats of the bench command itself (mode `bench`: only this, after profiles/pmc_reference.json of the
   #    same kernel sources is in place, so that the line carries the counters)
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-world-update > $OUT/${RTAG}_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-world-update --no-live-loop > $OUT/${RTAG}_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
   grep -c '"metric"' $OUT/${RTAG}_bench_under_rocprof.json || tail -5 $OUT/bench_under_rocprof.err
   cp $OUT/bench_trace/*/*_kernel_stats.csv $OUT/${RTAG}_bench_kernel_stats.csv
   rm -rf $OUT/bench_trace
