@@ -51,6 +51,71 @@ def test_device_update_equals_the_host_update(W, scene):
     r.destroy()
 
 
+def nasty_skinned_glb(seed, n_verts=700, n_tris=1500):
+    """A triangle soup with two skinned primitives (two geometries, one skin): joint indices beyond the skin's two joints,
+    all-zero weight rows (-> identity), weights that do not sum to one, zero-length normals, a scale animation that goes
+    through zero and up to 1e20 (degenerate boxes, huge extents), duplicate vertices and zero-area triangles."""
+    import gltf_util as G
+    f32 = np.float32
+    rng = np.random.default_rng(seed)
+    b = G.GltfBuilder()
+    prims = []
+    for k in range(2):
+        pos = (rng.random((n_verts, 3), dtype=f32) * f32(2) - f32(1)) * f32(0.4 + 0.3 * k)
+        pos[::17] = pos[0]                                   # duplicates
+        nrm = rng.standard_normal((n_verts, 3)).astype(f32)
+        nrm[::13] = 0                                        # normalize_or_zero
+        idx = rng.integers(0, n_verts, n_tris * 3).astype(np.uint32)
+        idx[:30] = idx[0]                                    # zero-area triangles
+        joints = rng.integers(0, 4, (n_verts, 4)).astype(np.uint16)       # 2 and 3 are beyond the skin
+        weights = rng.random((n_verts, 4), dtype=f32)
+        weights[rng.random(n_verts) < 0.2] = 0               # no influence at all
+        weights[rng.random((n_verts, 4)) < 0.3] = 0
+        acc = dict(POSITION=b.accessor(pos, G.F32, "VEC3", minmax=True), NORMAL=b.accessor(nrm, G.F32, "VEC3"),
+                   JOINTS_0=b.accessor(joints, G.U16, "VEC4"), WEIGHTS_0=b.accessor(weights, G.F32, "VEC4"))
+        prims.append({"attributes": acc, "indices": b.accessor(idx, G.U32, "SCALAR")})
+    b.doc["meshes"] = [{"primitives": prims}]
+    ibm = np.stack([np.eye(4, dtype=f32), np.eye(4, dtype=f32)])
+    ibm[1][1, 3] = -0.5
+    b.doc["nodes"] = [{"mesh": 0, "skin": 0}, {"children": [2]}, {"translation": [0, 0.5, 0]}]
+    b.doc["skins"] = [{"joints": [1, 2], "inverseBindMatrices": b.accessor(np.stack([m.T for m in ibm]), G.F32, "MAT4")}]
+    s, c = np.sin(0.6), np.cos(0.6)
+    t_in = b.accessor(np.array([0, 1, 2, 3], f32), G.F32, "SCALAR", minmax=True)
+    rot = b.accessor(np.array([[0, 0, -s, c], [s, 0, 0, c], [0, s, 0, c], [0, 0, -s, c]], f32), G.F32, "VEC4")
+    sc = b.accessor(np.array([[1, 1, 1], [0, 0, 0], [1e20, 1, 1e-20], [1, 1, 1]], f32), G.F32, "VEC3")
+    b.doc["animations"] = [{"samplers": [{"input": t_in, "output": rot}, {"input": t_in, "output": sc}],
+                            "channels": [{"sampler": 0, "target": {"node": 2, "path": "rotation"}},
+                                         {"sampler": 1, "target": {"node": 1, "path": "scale"}}]}]
+    return b.glb()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_update_on_degenerate_skinned_input(W, seed):
+    """The corner cases of the skinning loop and of the builders (see nasty_skinned_glb), at times that put the scale
+    animation at 1, near 0, at exactly 0, on the way to 1e20 and at 1e20: the device either produces the host's bytes or
+    refuses the frame (a NaN instance box) and the host path takes it."""
+    r = W.WebGPURenderer(0)
+    glb = nasty_skinned_glb(seed)
+    cpu_b, dev_b = W.WorldBridge(), W.WorldBridge()
+    dev_b.setDeviceUpdater(r)
+    cpu_b.loadScene("viewer", glbData=glb)
+    dev_b.loadScene("viewer", glbData=glb)
+    taken = 0
+    for t in (0.0, 0.37, 0.98, 1.0, 1.5, 2.0, 2.6, 0.2):
+        cpu_b.update(t)
+        dev_b.update(t)
+        if dev_b.deviceResident:
+            taken += 1
+            _same(r, cpu_b, "seed %d t=%g" % (seed, t))
+        else:
+            assert "NaN" in dev_b.deviceWarning, dev_b.deviceWarning
+            for k in BRIDGE_ARRAYS:
+                assert np.array_equal(np.asarray(getattr(cpu_b, k)).view(np.uint32), np.asarray(getattr(dev_b, k)).view(np.uint32)), (t, k)
+    assert taken >= 4
+    r.destroy()
+
+
 @pytest.mark.gpu
 def test_frames_from_the_device_world_equal_frames_from_uploaded_arrays(W):
     """The live loop with the device updater against the live loop that uploads the host arrays: accumulation buffers
