@@ -347,12 +347,15 @@ def main():
         r = pkg.WebGPURenderer(local_rank)
         r.buildPipeline(DEPTH, 1)
         res = {"scene": scene}
-        for mode, reps in (("host_cpu_builder", 2), ("host_gpu_blas_hook", 5), ("device_resident", 20)):
+        for mode, reps in (("host_cpu_builder", 2), ("host_gpu_blas_hook", 5), ("device_resident", 20), ("device_resident_static_cached", 20)):
             b = pkg.WorldBridge(zero_copy=True)
             if mode == "host_gpu_blas_hook":
                 b.setBlasBuilder(r)
-            elif mode == "device_resident":
+            elif mode.startswith("device_resident"):
                 b.setDeviceUpdater(r)
+                # the scene is static: with the cache (the default) only TLAS, instances and lights are redone per frame;
+                # without it every frame skins, builds and packs everything - the cost of a fully animated world
+                r.setWorldStaticCache(mode.endswith("cached"))
             b.loadScene(scene)
             pkg.upload_scene(r, b, width, height)
             res["triangles"] = len(b.mesh_topology) // 20
@@ -370,12 +373,12 @@ def main():
                 t2 = time.perf_counter()
                 t_upd += t1 - t0
                 t_sync += t2 - t1
-                if mode == "device_resident":
+                if mode.startswith("device_resident"):
                     if not b.deviceResident:
                         raise SystemExit("bench.py: the device-resident update fell back to the host: " + b.deviceWarning)
                     t_gpu += r.worldLastMs()
             e = {"update_ms": round(t_upd / reps * 1e3, 3), "upload_ms": round(t_sync / reps * 1e3, 3)}
-            if mode == "device_resident":
+            if mode.startswith("device_resident"):
                 e["gpu_stream_ms"] = round(t_gpu / reps, 3)
             res[mode] = e
             b.close()

@@ -231,6 +231,11 @@ int rt_build_blas_levels(const rt_ctx* ctx);
  * description this path does not take (an instance of an empty geometry, a NaN instance box; the caller then runs the
  * host update and uploads as before) or an error. */
 int rt_world_update(rt_ctx* ctx, const rt_world_frame* frame);
+/* A geometry without a skin has the same vertices in every frame of a static description, hence the same BLAS, topology
+ * rows and emissive list: after the first update rt_world_update leaves its rows in place and copies its node block from a
+ * cache (World::update rebuilds it every frame - the same bytes).  Any host upload into the scene buffers (rt_upload*,
+ * a new static_epoch) drops the cache.  enabled = 0 rebuilds everything every frame (measurements); default 1. */
+int rt_world_set_static_cache(rt_ctx* ctx, int enabled);
 /* Stream time (ms, HIP events) of the last rt_world_update: kernels and the small copies, without host work. */
 double rt_world_last_ms(const rt_ctx* ctx);
 /* Read a bridge array back from the device-resident world (tests; a host that wants the arrays after all).  out == NULL:

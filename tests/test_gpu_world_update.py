@@ -145,6 +145,40 @@ def test_frames_from_the_device_world_equal_frames_from_uploaded_arrays(W):
 
 
 @pytest.mark.gpu
+def test_static_geometry_cache(W):
+    """Geometries without a skin keep their BLAS / rows between frames (rt_world_set_static_cache, default on): the arrays
+    are those of a full rebuild; a host upload into the renderer in between (another scene!) drops the cache; with the
+    cache off every frame rebuilds everything."""
+    r = W.WebGPURenderer(0)
+    glb = test_gltf.big_skinned_glb(W, 64, 32)[0]
+    cpu_b, dev_b = W.WorldBridge(), W.WorldBridge()
+    dev_b.setDeviceUpdater(r)
+    cpu_b.loadScene("viewer", glbData=glb)
+    dev_b.loadScene("viewer", glbData=glb)
+    other = W.WorldBridge()
+    other.loadScene("mixed")
+    for k, t in enumerate((0.0, 0.5, 0.9, 1.3, 1.8, 0.1)):
+        if k == 3:
+            W.upload_scene(r, other, 64, 48)            # somebody else's arrays land in the scene buffers
+        if k == 4:
+            r.setWorldStaticCache(False)
+        cpu_b.update(t)
+        dev_b.update(t)
+        assert dev_b.deviceResident, dev_b.deviceWarning
+        _same(r, cpu_b, "cache step %d" % k)
+    r.setWorldStaticCache(True)
+    for scene in ("sponza_like", "instanced1000"):      # all-static worlds: the second update only redoes TLAS and packing
+        cpu_b.loadScene(scene)
+        dev_b.loadScene(scene)
+        for t in (0.0, 0.3, 0.6):
+            cpu_b.update(t)
+            dev_b.update(t)
+            assert dev_b.deviceResident, dev_b.deviceWarning
+            _same(r, cpu_b, "%s cached t=%g" % (scene, t))
+    r.destroy()
+
+
+@pytest.mark.gpu
 def test_animated_live_loop_traces_nothing_in_vain(W):
     """A world that moves every 4th frame, lookahead on: the loop tells the library when the run ends
     (rt_set_lookahead_limit), so the images are those of one dispatch per frame AND exactly the displayed frames were

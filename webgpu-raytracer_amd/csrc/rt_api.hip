@@ -76,6 +76,10 @@ struct rt_ctx {
     void* pinned = nullptr;               // joint-matrix staging and the end-of-update read-back
     size_t pinned_bytes = 0;
     wu::TlasArgs tlas;
+    // static-geometry cache: a geometry without a skin has the same BLAS in every frame of a static description
+    bool cache_enabled = true, static_cached = false;
+    DeviceBuffer static_nodes;
+    std::vector<uint32_t> static_count, static_off;   // per geometry: cached node count, first node in static_nodes
     double last_ms = 0;                   // stream time of the last update (rt_world_last_ms)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
   } world;
@@ -582,7 +586,8 @@ void rt_destroy(rt_ctx* c) {
                          &c->bv_counters, &c->bv_big, &c->val_roots, &c->val_bad, &c->tnodes, &c->node_key, &c->node_newidx,
                          &c->inst_root, &c->root_w, &c->treelet_work, &c->pairs, &c->pair_of, &c->pair_parent, &c->root_rec,
                          &c->world.stat, &c->world.joints, &c->world.raw_inst, &c->world.geom_rows, &c->world.node_base,
-                         &c->world.em_flag, &c->world.em_list, &c->world.em_blk, &c->world.tlas_scratch, &c->world.stats};
+                         &c->world.em_flag, &c->world.em_list, &c->world.em_blk, &c->world.tlas_scratch, &c->world.stats,
+                         &c->world.static_nodes};
   for (DeviceBuffer* b : all) free_buffer(*b);
   if (c->world.pinned) (void)hipHostFree(c->world.pinned);
   if (c->world.ev0) (void)hipEventDestroy(c->world.ev0);
@@ -890,6 +895,7 @@ int rt_build_blas(rt_ctx* c, const float* verts4, uint32_t n_verts, const uint32
 static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
   auto& W = c->world;
   W.valid = false;
+  W.static_cached = false;
   if (!f->n_instances || !f->instances || (f->n_geometries && !f->geometries))
     return fail(c, RT_ERR_INVALID, "rt_world_update: empty scene description");
   const uint32_t G = f->n_geometries, N = f->n_instances;
@@ -1106,6 +1112,12 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
         HIP_TRY(c, hipMemsetAsync(d_stats + 4 * (size_t)g, 0, 16, c->stream));
         continue;
       }
+      if (W.cache_enabled && W.static_cached && !D.skinned) {   // same vertices as last frame: rows stay, nodes come from the cache
+        const uint32_t cnt = W.static_count[g];
+        hipLaunchKernelGGL(wu::k_static_nodes, dim3((2 * cnt + 255) / 256), dim3(256), 0, c->stream,
+                           (const float4*)W.static_nodes.ptr + 2 * (size_t)W.static_off[g], cnt, d_node_base + g, nodes + 2 * (size_t)W.n_tlas);
+        continue;
+      }
       hipLaunchKernelGGL(wu::k_skin, dim3((D.n_verts + 255) / 256), dim3(256), 0, c->stream, D, (const float*)W.joints.ptr, (float4*)c->pos.ptr,
                          (float4*)c->nrm.ptr, (float2*)c->uv.ptr);
       bvhb::Build B;
@@ -1145,8 +1157,9 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     HIP_TRY(c, hipEventRecord(W.ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     bool again = false;
+    const bool was_cached = W.cache_enabled && W.static_cached;
     for (uint32_t g = 0; g < G; g++) {
-      if (!W.geoms[g].n_verts) continue;
+      if (!W.geoms[g].n_verts || (was_cached && !W.geoms[g].skinned)) continue;
       const uint32_t* st = rb_stats + 4 * (size_t)g;
       if (st[0]) {   // deeper than launched: build again with more levels
         if (W.levels[g] >= bvhb::kMaxLevels) return fail(c, RT_ERR_INVALID, "rt_world_update: a BLAS is deeper than 1024 levels");
@@ -1209,11 +1222,36 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     c->validate_dirty = false;
     c->scene_valid = true;
     c->tris_dirty = c->inst_dirty = c->lights_dirty = c->nodes_dirty = c->pairs_dirty = c->roots_dirty = true;
+    if (W.cache_enabled && !W.static_cached) {   // first full update of this description: keep the static geometries' node blocks
+      W.static_count.assign(G, 0u);
+      W.static_off.assign(G, 0u);
+      size_t total = 0;
+      for (uint32_t g = 0; g < G; g++)
+        if (W.geoms[g].n_verts && !W.geoms[g].skinned) {
+          W.static_off[g] = (uint32_t)total;
+          W.static_count[g] = rb_base[g + 1] - rb_base[g];
+          total += W.static_count[g];
+        }
+      if ((r = ensure_buffer(c, W.static_nodes, std::max<size_t>(32, total * sizeof(rt_node)), false)) < 0) return r;
+      for (uint32_t g = 0; g < G; g++)
+        if (W.static_count[g])
+          HIP_TRY(c, hipMemcpyAsync((char*)W.static_nodes.ptr + (size_t)W.static_off[g] * sizeof(rt_node),
+                                    (const char*)c->nodes.ptr + ((size_t)W.n_tlas + rb_base[g]) * sizeof(rt_node),
+                                    (size_t)W.static_count[g] * sizeof(rt_node), hipMemcpyDeviceToDevice, c->stream));
+      W.static_cached = true;
+    }
     return ret;
   }
 }
 
 double rt_world_last_ms(const rt_ctx* c) { return c ? c->world.last_ms : 0.0; }
+
+int rt_world_set_static_cache(rt_ctx* c, int enabled) {
+  if (!c) return RT_ERR_INVALID;
+  c->world.cache_enabled = enabled != 0;
+  c->world.static_cached = false;   // the next update builds everything (and refills the cache when enabled)
+  return RT_OK;
+}
 
 // the bridge arrays as the device update left them (tests; a host that wants them back)
 int rt_world_read(rt_ctx* c, int which, void* out, size_t cap_bytes, size_t* bytes_out) {
@@ -1248,7 +1286,8 @@ int rt_build_blas_levels(const rt_ctx* c) { return c ? (int)(c->bv_levels | (c->
 
 int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
   if (!c) return RT_ERR_INVALID;
-  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
+  c->epoch++;
+  c->world.static_cached = false;   // host arrays replace what the device update left in the scene buffers   // drops frames traced ahead (rt_set_lookahead)
   if (bytes && !data) return fail(c, RT_ERR_INVALID, "null data");
   HIP_TRY(c, hipSetDevice(c->device));
   int r;
@@ -1325,7 +1364,8 @@ int rt_upload(rt_ctx* c, rt_kind kind, const void* data, size_t bytes) {
 
 int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const float* uv2, uint32_t vertex_count) {
   if (!c) return RT_ERR_INVALID;
-  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
+  c->epoch++;
+  c->world.static_cached = false;   // host arrays replace what the device update left in the scene buffers   // drops frames traced ahead (rt_set_lookahead)
   if (vertex_count && (!pos4 || !nrm4 || !uv2)) return fail(c, RT_ERR_INVALID, "null geometry array");
   HIP_TRY(c, hipSetDevice(c->device));
   // The reference packs the three arrays into one buffer at 256-byte aligned offsets because WebGPU
@@ -1346,7 +1386,8 @@ int rt_upload_geometry(rt_ctx* c, const float* pos4, const float* nrm4, const fl
 
 int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* blas, uint32_t n_blas) {
   if (!c) return RT_ERR_INVALID;
-  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
+  c->epoch++;
+  c->world.static_cached = false;   // host arrays replace what the device update left in the scene buffers   // drops frames traced ahead (rt_set_lookahead)
   if ((n_tlas && !tlas) || (n_blas && !blas)) return fail(c, RT_ERR_INVALID, "null BVH array");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t total = ((size_t)n_tlas + n_blas) * sizeof(rt_node);

@@ -360,6 +360,17 @@ __global__ __launch_bounds__(256) void k_lights(TlasArgs A, const uint32_t* __re
     if (off + k < A.n_lights) lights[off + k] = make_uint2(p, em_list[G.em_first + k]);
 }
 
+// A geometry that is not skinned has the same vertices, hence the same BLAS, topology rows and emissive list in every
+// frame: after the first update of a static description its rows are left where they are and its node block is copied
+// from a cache to where this frame's prefix of node counts puts it (node_base[0] in, node_base[1] out).
+__global__ __launch_bounds__(256) void k_static_nodes(const float4* __restrict__ cache, uint32_t n_nodes, uint32_t* node_base,
+                                                       float4* __restrict__ out_blas) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t base = node_base[0];
+  if (i < 2u * n_nodes) out_blas[2 * (size_t)base + i] = cache[i];
+  if (i == 0u) node_base[1] = base + n_nodes;
+}
+
 // what the host wants to know of one finished build, kept where the next build does not overwrite it
 __global__ void k_build_stats(const bvhb::Ctl* __restrict__ ctl, uint32_t levels, uint32_t* __restrict__ out) {
   if (threadIdx.x != 0u || blockIdx.x != 0u) return;

@@ -176,7 +176,7 @@ def load_library(path=None):
         "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]), "rt_set_lookahead": (i32, [vp, u32]),
         "rt_set_lookahead_limit": (i32, [vp, u32]),
         "rt_build_blas_levels": (i32, [vp]),
-        "rt_world_update": (i32, [vp, vp]), "rt_world_last_ms": (ctypes.c_double, [vp]),
+        "rt_world_update": (i32, [vp, vp]), "rt_world_set_static_cache": (i32, [vp, i32]), "rt_world_last_ms": (ctypes.c_double, [vp]),
         "rt_world_read": (i32, [vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     }
     for name, (res, args) in sigs.items():
@@ -196,7 +196,7 @@ EXPORTED_SYMBOLS = (
     "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_read_traversal_nodes rt_debug_read_pairs "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead "
-    "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit").split()
+    "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit rt_world_set_static_cache").split()
 
 
 def _ptr(a):
@@ -306,6 +306,10 @@ class WebGPURenderer:
         if n.value:
             self._check(self.L.rt_world_read(self.ctx, which, _ptr(out), out.nbytes, ctypes.byref(n)), "worldRead(%s)" % name)
         return out
+
+    def setWorldStaticCache(self, enabled):
+        """device-resident update(t): keep the BLAS / rows of geometries without a skin between frames (default on)"""
+        self._check(self.L.rt_world_set_static_cache(self.ctx, 1 if enabled else 0), "setWorldStaticCache")
 
     def worldLastMs(self):
         """GPU stream time of the last device-resident update(t) (ms)."""
