@@ -77,7 +77,7 @@ struct rt_ctx {
     size_t pinned_bytes = 0;
     wu::TlasArgs tlas;
     // static-geometry cache: a geometry without a skin has the same BLAS in every frame of a static description
-    bool cache_enabled = true, static_cached = false;
+    bool cache_enabled = true, static_cached = false, any_skinned = false;
     DeviceBuffer static_nodes;
     std::vector<uint32_t> static_count, static_off;   // per geometry: cached node count, first node in static_nodes
     double last_ms = 0;                   // stream time of the last update (rt_world_last_ms)
@@ -1029,6 +1029,8 @@ static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
     W.levels[g] = blas_guess_levels(W.geoms[g].n_tris);
     W.big_levels[g] = blas_guess_big_levels(W.geoms[g].n_tris);
   }
+  W.any_skinned = false;
+  for (uint32_t g = 0; g < G; g++) W.any_skinned = W.any_skinned || (W.geoms[g].n_verts && W.geoms[g].skinned);
   W.n_verts = (uint32_t)verts;
   W.n_tris = (uint32_t)tris;
   W.n_lights = (uint32_t)lights;
@@ -1069,6 +1071,12 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
   }
   const uint32_t G = (uint32_t)W.geoms.size(), N = W.n_inst;
   if (f->n_geometries != G || f->n_instances != N) return fail(c, RT_ERR_INVALID, "rt_world_update: the scene changed under an unchanged static_epoch");
+  if (W.cache_enabled && W.static_cached && !W.any_skinned) {
+    // nothing in this world moves: every array of this frame is the one the last update left in the scene buffers (and the
+    // renderer's derived records are those of that scene) - World::update would rebuild all of it to the same bytes
+    W.last_ms = 0.0;
+    return ret;
+  }
   // this frame's joint matrices
   const uint32_t n_joints = f->n_skins ? f->skin_first[f->n_skins] : 0u;
   if (n_joints && !f->joint_mats) return fail(c, RT_ERR_INVALID, "rt_world_update: null joint matrices");
