@@ -332,6 +332,47 @@ def big_skinned_glb(W, nu=192, nv=96):
     return b.glb(), len(idx) // 3
 
 
+def character_in_hall_glb(W, hall=(512, 256), nu=96, nv=48):
+    """The usual animated scene: a small skinned, animated mesh (the tube of big_skinned_glb, nu x nv quads) inside a large
+    STATIC one (a wavy hall[0] x hall[1]-quad sheet, 2 * hall[0] * hall[1] triangles) — two nodes, two geometries."""
+    b = G.GltfBuilder()
+    hu, hv = hall
+    x = np.linspace(-1.2, 1.2, hu + 1, dtype=f32)
+    z = np.linspace(-1.2, 1.2, hv + 1, dtype=f32)
+    xx, zz = np.meshgrid(x, z)
+    yy = (0.05 * np.sin(7 * xx) * np.cos(5 * zz)).astype(f32)
+    hpos = np.stack([xx, yy, zz], -1).reshape(-1, 3).astype(f32)
+    hnrm = np.tile(np.array([0, 1, 0], f32), (len(hpos), 1))
+    a = (np.arange(hv)[:, None] * (hu + 1) + np.arange(hu)[None, :]).reshape(-1)
+    hidx = np.stack([a, a + 1, a + hu + 2, a, a + hu + 2, a + hu + 1], 1).reshape(-1).astype(np.uint32)
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False, dtype=f32)
+    v = np.linspace(0, 1, nv + 1, dtype=f32)
+    uu, vv = np.meshgrid(u, v)
+    pos = np.stack([0.15 * np.cos(uu), vv + 0.1, 0.15 * np.sin(uu)], -1).reshape(-1, 3).astype(f32)
+    nrm = np.stack([np.cos(uu), np.zeros_like(uu), np.sin(uu)], -1).reshape(-1, 3).astype(f32)
+    q = (np.arange(nv)[:, None] * nu + np.arange(nu)[None, :])
+    qn = (np.arange(nv)[:, None] * nu + (np.arange(nu)[None, :] + 1) % nu)
+    idx = np.stack([q, qn, qn + nu, q, qn + nu, q + nu], -1).reshape(-1).astype(np.uint32)
+    w1 = np.clip((pos[:, 1] - 0.4) * 2.5, 0, 1).astype(f32)
+    weights = np.stack([1 - w1, w1, 0 * w1, 0 * w1], 1).astype(f32)
+    joints = np.tile(np.array([0, 1, 0, 0], np.uint16), (len(pos), 1))
+    hall_acc = dict(POSITION=b.accessor(hpos, G.F32, "VEC3", minmax=True), NORMAL=b.accessor(hnrm, G.F32, "VEC3"))
+    tube_acc = dict(POSITION=b.accessor(pos, G.F32, "VEC3", minmax=True), NORMAL=b.accessor(nrm, G.F32, "VEC3"),
+                    JOINTS_0=b.accessor(joints, G.U16, "VEC4"), WEIGHTS_0=b.accessor(weights, G.F32, "VEC4"))
+    b.doc["meshes"] = [{"primitives": [{"attributes": hall_acc, "indices": b.accessor(hidx, G.U32, "SCALAR")}]},
+                       {"primitives": [{"attributes": tube_acc, "indices": b.accessor(idx, G.U32, "SCALAR")}]}]
+    ibm = np.stack([np.eye(4, dtype=f32), np.eye(4, dtype=f32)])
+    ibm[1][1, 3] = -0.6
+    b.doc["nodes"] = [{"mesh": 0}, {"mesh": 1, "skin": 0}, {"children": [3]}, {"translation": [0, 0.6, 0]}]
+    b.doc["scenes"][0]["nodes"] = [0, 1, 2]
+    b.doc["skins"] = [{"joints": [2, 3], "inverseBindMatrices": b.accessor(np.stack([m.T for m in ibm]), G.F32, "MAT4")}]
+    s45, c45 = np.sin(np.pi / 8), np.cos(np.pi / 8)
+    b.doc["animations"] = [{"name": "sway", "samplers": [{"input": b.accessor(np.array([0, 1, 2], f32), G.F32, "SCALAR", minmax=True),
+                                                          "output": b.accessor(np.array([[0, 0, -s45, c45], [0, 0, s45, c45], [0, 0, -s45, c45]], f32), G.F32, "VEC4")}],
+                            "channels": [{"sampler": 0, "target": {"node": 3, "path": "rotation"}}]}]
+    return b.glb(), len(hidx) // 3, len(idx) // 3
+
+
 BRIDGE_ARRAYS = ("vertices", "normals", "uvs", "mesh_topology", "tlas", "blas", "instances", "lights", "draw_commands")
 
 

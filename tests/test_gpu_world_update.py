@@ -23,7 +23,7 @@ def _same(r, cpu_b, tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["cornell", "mixed", "special", "instanced1000", "sponza_like", "glass_blob", "skinned_tube",
-                                   "skinned_small"])
+                                   "skinned_small", "character_in_hall"])
 def test_device_update_equals_the_host_update(W, scene):
     """Every bridge array, byte for byte: the static scenes (1 to 1 001 instances: the TLAS sort, rotation and light
     lists), the two 200 k+ triangle meshes (large-node levels of the builder) and skinned, animated glTFs at three times."""
@@ -31,6 +31,8 @@ def test_device_update_equals_the_host_update(W, scene):
     glb, name, times = None, scene, (0.0,)
     if scene == "skinned_tube":
         glb, name, times = test_gltf.big_skinned_glb(W)[0], "viewer", (0.0, 0.4, 1.7)
+    elif scene == "character_in_hall":       # a large static mesh (kept between frames) + a small skinned one
+        glb, name, times = test_gltf.character_in_hall_glb(W, (160, 96))[0], "viewer", (0.0, 0.4, 1.7)
     elif scene == "skinned_small":
         glb, name, times = test_gltf.build_skinned(W)[0].glb(), "viewer", (0.0, 0.3, 0.9)
     cpu_b, dev_b = W.WorldBridge(), W.WorldBridge()

@@ -35,7 +35,8 @@ if [ "$WHAT" = world ] || [ "$WHAT" = all ]; then
   MODES=device timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_world -- python3 $R/tools/animate_bench.py 512 256 40 > $OUT/${RTAG}_world_update.log 2>&1
   cp $OUT/trace_world/*/*_kernel_stats.csv $OUT/${RTAG}_world_update_kernel_stats.csv
   rm -rf $OUT/trace_world
-  timeout -k 10 300 python3 $R/tools/animate_bench.py 512 256 40 2>&1 | grep "triangles skinned" > $OUT/${RTAG}_animate_bench.txt
+  timeout -k 10 300 python3 $R/tools/animate_bench.py 512 256 40 2>&1 | grep "triangles" > $OUT/${RTAG}_animate_bench.txt
+  SCENE=hall timeout -k 10 300 python3 $R/tools/animate_bench.py 512 256 40 2>&1 | grep "triangles" >> $OUT/${RTAG}_animate_bench.txt
 fi
 if [ "$WHAT" = scene ]; then SCENES="$2"; fi
 if [ "$WHAT" = big ] || [ "$WHAT" = all ] || [ "$WHAT" = scene ]; then
