@@ -147,6 +147,73 @@ def test_frames_from_the_device_world_equal_frames_from_uploaded_arrays(W):
 
 
 @pytest.mark.gpu
+def test_descriptions_the_device_path_refuses(W):
+    """rt_world_update called directly with hand-made frames: what it does not take comes back as an error with the
+    reason (the scene compiler then runs the host path), and a frame it takes is right afterwards."""
+    import ctypes
+    from test_world_device_hook import Frame, Geometry
+    r = W.WebGPURenderer(0)
+    f32 = np.float32
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], f32)
+    nrm = np.tile(np.array([0, 0, 1], f32), (4, 1))
+    joints = np.zeros((4, 4), np.uint32)
+    weights = np.zeros((4, 4), f32)
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    attr = np.zeros((2, 16), f32)
+    attr[:, :3] = 0.5
+    fp, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)
+
+    def geometry(n_tris=2):
+        g = Geometry()
+        g.positions, g.normals, g.uvs = pos.ctypes.data_as(fp), nrm.ctypes.data_as(fp), None
+        g.joints, g.weights = joints.ctypes.data_as(up), weights.ctypes.data_as(fp)
+        g.indices, g.attributes = idx.ctypes.data_as(up), attr.ctypes.data_as(fp)
+        g.n_verts, g.n_uvs, g.n_tris, g.skin = 4, 0, n_tris, -1
+        return g
+
+    def frame(epoch, geos, inst):
+        fr = Frame()
+        arr = (Geometry * len(geos))(*geos)
+        fr.static_epoch, fr.n_geometries, fr.n_instances, fr.n_skins = epoch, len(geos), len(inst), 0
+        fr.geometries, fr.instances = arr, inst.ctypes.data_as(fp)
+        return fr, arr
+
+    def instance(geometry_id, m=None):
+        row = np.zeros(36, f32)
+        m = np.eye(4, dtype=f32) if m is None else m
+        row[:16] = m.T.reshape(-1)
+        row[16:32] = np.linalg.inv(np.nan_to_num(m)).T.reshape(-1).astype(f32)
+        row[32:].view(np.uint32)[:] = (0, 0, geometry_id, 0)
+        return row
+
+    def call(fr):
+        return r.L.rt_world_update(r.ctx, ctypes.byref(fr[0])), r.L.rt_last_error(r.ctx).decode()
+
+    rc, why = call(frame(1001, [geometry()], np.stack([instance(0)])))
+    assert rc >= 0, why
+    nodes = r.worldRead("blas").reshape(-1, 8)
+    assert len(nodes) == 1 and nodes[0, 7:8].view(np.uint32)[0] == 2          # one leaf: first 0, count 2
+    bad = np.eye(4, dtype=f32)
+    bad[0, 3] = np.nan
+    rc, why = call(frame(1002, [geometry()], np.stack([instance(0, bad)])))
+    assert rc < 0 and "NaN" in why
+    rc, why = call(frame(1003, [geometry(), geometry(0)], np.stack([instance(0), instance(1)])))
+    assert rc < 0 and "no triangles" in why
+    rc, why = call(frame(1004, [geometry()], np.stack([instance(3)])))
+    assert rc < 0 and "missing or empty" in why
+    rc, why = call(frame(1005, [geometry()], np.stack([instance(0)] * 16385)))
+    assert rc < 0 and "16 384" in why
+    idx[5] = 9                                                               # vertex index out of range
+    rc, why = call(frame(1006, [geometry()], np.stack([instance(0)])))
+    assert rc < 0 and "out of range" in why
+    idx[5] = 3
+    rc, why = call(frame(1007, [geometry()], np.stack([instance(0), instance(0)])))
+    assert rc >= 0, why
+    assert len(r.worldRead("tlas")) // 8 == 3 and len(r.worldRead("instances")) // 36 == 2
+    r.destroy()
+
+
+@pytest.mark.gpu
 def test_static_geometry_cache(W):
     """Geometries without a skin keep their BLAS / rows between frames (rt_world_set_static_cache, default on): the arrays
     are those of a full rebuild; a host upload into the renderer in between (another scene!) drops the cache; with the
