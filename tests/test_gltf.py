@@ -399,7 +399,7 @@ def test_gpu_blas_builder_equals_the_cpu_builder(W):
         return nodes, topo[topo[:, 3] == 2][:, :3] - ENV_VERTS, 12      # 12 = triangles of the room before this geometry
 
     cases = []
-    for n_tris in (1, 3, 4, 5, 9, 64, 1000, 20000):
+    for n_tris in (1, 3, 4, 5, 9, 63, 64, 65, 129, 1000, 4095, 4096, 4097, 9000, 20000):   # around the builder's thresholds: 64 (in-wave subtrees), 4 096 (large-node kernels)
         verts = rng.random((n_tris * 3, 3), dtype=f32) * f32(2) - f32(1)
         if n_tris == 64:
             verts[:, 2] = 0.25                      # flat: padded boxes
