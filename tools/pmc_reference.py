@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/pmc_reference.json from the per-kernel PMC averages of tools/make_profiles_r02.sh (profiles/r02_*_pmc.json),
+"""profiles/pmc_reference.json from the per-kernel PMC averages of tools/make_profiles_round.sh (profiles/<RTAG>_*_pmc.json),
 the in-kernel clock check and the VALU peak microbenchmark.  bench.py reads it for the fields it cannot measure from
 inside its own process; every such field is reported with this file's "source".
-usage: pmc_reference.py <dir with r02_*_pmc.json etc.> <commit> [out.json]"""
+usage: pmc_reference.py <dir with <RTAG>_*_pmc.json etc.> <commit> [out.json]"""
 import json
 import os
 import re
