@@ -257,6 +257,26 @@ int rt_debug_trace_sections(rt_ctx* ctx, uint64_t* out16, int reset);
 /* Diagnostic build (-DRT_PT_STAMPS) only: the same for k_pathtrace_persistent: out8[0..4] = cycles in {regenerate + start,
  * shade, shadow traversal, extension traversal + surface frame, finish}, [5] trips, [6] waves. */
 int rt_debug_pt_sections(rt_ctx* ctx, uint64_t* out8, int reset);
+/* Diagnostic build (-DRT_LANE_STATS) only: lane utilisation of the parts of a trip of k_pathtrace_persistent:
+ * out32[2 k] = times part k ran (wave level), out32[2 k + 1] = active lanes summed; k = 0 shade, 1 / 2 node step / triangle
+ * chunk of the shadow walk, 3 / 4 of the extension walk, 5 surface frame of a new hit, 6 start of a sample, 7 end of a sample.
+ * Returns 1 in the diagnostic build, 0 in the product build (no counter executes, the array stays zero). */
+int rt_debug_lane_stats(rt_ctx* ctx, uint64_t* out32, int reset);
+/* Proof obligation of the device build's short division / reciprocal / square-root sequences (csrc/k_ieee.hip.h): run
+ * them on the GPU against the compiler's correctly rounded IEEE expansions over inputs [first, first + count) of the
+ * input set of `op` (csrc/k_ieee_inputs.h: RT_IEEE_OP_*; one-operand ops: index = bit pattern, 2^32 of them; divisions:
+ * 2^24 mantissa samples x 2^8 exponent classes).  n = inputs checked; guard_pass = inputs the guard sends down the short
+ * sequence, wrong_fast = of those, results that differ from IEEE (must be 0); wrong_fn = results of the composed function
+ * (guard + wave-uniform fallback, what the kernels call) that differ (must be 0); checksum = sum of
+ * rt_ieee_mix(IEEE result, index), to be compared with the host CPU's own IEEE results (tests/model/ieee_ref.cpp);
+ * bad = operand a, operand b, got, ieee of the first mismatches.  No renderer state is touched.  Returns RT_OK, or
+ * RT_ERR_INVALID for an unknown op / a build with -DRT_IEEE_PLAIN (nothing to check). */
+typedef struct rt_ieee_report {
+  uint64_t n, guard_pass, wrong_fast, wrong_fn, checksum;
+  uint32_t n_bad;
+  uint32_t bad[32];
+} rt_ieee_report;
+int rt_debug_ieee_check(rt_ctx* ctx, int op, uint64_t first, uint64_t count, rt_ieee_report* out);
 /* Path-trace kernel form (all four are bit-identical; tests/test_gpu_parity.py::test_kernel_forms_agree_bitwise):
  *   3 = auto (default): wavefront form when the scene's records do not fit LDS, SPP == 1 and the dispatch carries
  *       >= 4 frames (rt_compute_batch); the persistent kernel otherwise

@@ -17,6 +17,11 @@
  *   - dot/cross/matrix products associate left to right;
  *   - normalize(v) = v * (1 / sqrt(dot(v,v)));
  *   - transcendental functions are the fixed polynomial kernels below.
+ *
+ * Division, reciprocal and square root are named functions here (rt_div, rt_rcp, rt_sqrt, rt_rsqrt, ...): they ARE the
+ * IEEE operations — on the host the language operators; a gfx950 device compilation computes the same bits with shorter
+ * instruction sequences (webgpu-raytracer_amd/csrc/k_ieee.hip.h defines MI355RT_DEVICE_IEEE; every sequence is checked
+ * against the plain operator over its whole input space by tests/test_gpu_ieee.py).  The oracle never sees that header.
  */
 #ifndef MI355RT_MATH_H
 #define MI355RT_MATH_H
@@ -60,7 +65,22 @@ RT_HD float rt_max(float a, float b) {
 RT_HD float rt_clamp(float x, float lo, float hi) { return rt_min(rt_max(x, lo), hi); }
 RT_HD float rt_saturate(float x) { return rt_clamp(x, 0.0f, 1.0f); }
 RT_HD float rt_abs(float x) { return rt_u2f(rt_f2u(x) & 0x7fffffffu); }
+/* ---- the IEEE operations with a name (see the header comment) */
+#if defined(MI355RT_DEVICE_IEEE)
+RT_HD float rt_sqrt(float x) { return rt_ieee::sqrt(x); }
+RT_HD float rt_rcp(float x) { return rt_ieee::rcp(x); }                      /* 1 / x */
+RT_HD float rt_div(float a, float b) { return rt_ieee::div(a, b); }          /* a / b */
+RT_HD float rt_rsqrt(float x) { return rt_ieee::rsqrt(x); }                  /* 1 / sqrt(x): two roundings */
+RT_HD float rt_div_pi(float x) { return rt_ieee::div_const(x, 3.14159274101257324219f, 1.0f / 3.14159274101257324219f); }
+RT_HD float rt_from_unorm8(uint32_t q) { return rt_ieee::unorm8(q); }
+#else
 RT_HD float rt_sqrt(float x) { return __builtin_sqrtf(x); }
+RT_HD float rt_rcp(float x) { return 1.0f / x; }
+RT_HD float rt_div(float a, float b) { return a / b; }
+RT_HD float rt_rsqrt(float x) { return 1.0f / __builtin_sqrtf(x); }
+RT_HD float rt_div_pi(float x) { return x / 3.14159274101257324219f; }
+RT_HD float rt_from_unorm8(uint32_t q) { return (float)q / 255.0f; }
+#endif
 RT_HD float rt_floor(float x) { return __builtin_floorf(x); }
 RT_HD float rt_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
@@ -204,10 +224,46 @@ RT_HD rt2 rt2_make(float x, float y) { rt2 r; r.x = x; r.y = y; return r; }
 RT_HD rt3 operator+(rt3 a, rt3 b) { return rt3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_HD rt3 operator-(rt3 a, rt3 b) { return rt3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_HD rt3 operator*(rt3 a, rt3 b) { return rt3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
-RT_HD rt3 operator/(rt3 a, rt3 b) { return rt3_make(a.x / b.x, a.y / b.y, a.z / b.z); }
+RT_HD rt3 operator/(rt3 a, rt3 b) { return rt3_make(rt_div(a.x, b.x), rt_div(a.y, b.y), rt_div(a.z, b.z)); }
 RT_HD rt3 operator*(rt3 a, float s) { return rt3_make(a.x * s, a.y * s, a.z * s); }
 RT_HD rt3 operator*(float s, rt3 a) { return rt3_make(s * a.x, s * a.y, s * a.z); }
-RT_HD rt3 operator/(rt3 a, float s) { return rt3_make(a.x / s, a.y / s, a.z / s); }
+RT_HD rt3 operator/(rt3 a, float s) {   /* three quotients by one divisor */
+#if defined(MI355RT_DEVICE_IEEE)
+  rt3 q;
+  rt_ieee::div3(a.x, a.y, a.z, s, q.x, q.y, q.z);
+  return q;
+#else
+  return rt3_make(a.x / s, a.y / s, a.z / s);
+#endif
+}
+RT_HD rt3 rt_div3z(rt3 a, float s) {    /* a / s where components of a may be zero (device: the zero-tolerant sequence) */
+#if defined(MI355RT_DEVICE_IEEE)
+  rt3 q;
+  rt_ieee::div3z(a.x, a.y, a.z, s, q.x, q.y, q.z);
+  return q;
+#else
+  return rt3_make(a.x / s, a.y / s, a.z / s);
+#endif
+}
+RT_HD rt3 rt_div3_plain(rt3 a, float s) { return rt3_make(a.x / s, a.y / s, a.z / s); }   /* the language operator on both sides */
+RT_HD rt3 rt_rcp3(rt3 d) {              /* vec3(1) / d */
+#if defined(MI355RT_DEVICE_IEEE)
+  rt3 r;
+  rt_ieee::rcp3(d.x, d.y, d.z, r.x, r.y, r.z);
+  return r;
+#else
+  return rt3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
+}
+RT_HD rt3 rt_div_pi3(rt3 a) {           /* a / RT_PI */
+#if defined(MI355RT_DEVICE_IEEE)
+  rt3 q;
+  rt_ieee::div_const3(a.x, a.y, a.z, 3.14159274101257324219f, 1.0f / 3.14159274101257324219f, q.x, q.y, q.z);
+  return q;
+#else
+  return rt3_make(a.x / 3.14159274101257324219f, a.y / 3.14159274101257324219f, a.z / 3.14159274101257324219f);
+#endif
+}
 RT_HD rt3 operator-(rt3 a) { return rt3_make(-a.x, -a.y, -a.z); }
 RT_HD rt2 operator+(rt2 a, rt2 b) { return rt2_make(a.x + b.x, a.y + b.y); }
 RT_HD rt2 operator*(rt2 a, float s) { return rt2_make(a.x * s, a.y * s); }
@@ -218,7 +274,7 @@ RT_HD rt3 rt_cross(rt3 a, rt3 b) {
 }
 RT_HD float rt_length(rt3 a) { return rt_sqrt(rt_dot(a, a)); }
 RT_HD rt3 rt_normalize(rt3 a) {
-  float inv = 1.0f / rt_sqrt(rt_dot(a, a));
+  float inv = rt_rsqrt(rt_dot(a, a));
   return a * inv;
 }
 RT_HD rt3 rt_min3(rt3 a, rt3 b) { return rt3_make(rt_min(a.x, b.x), rt_min(a.y, b.y), rt_min(a.z, b.z)); }
@@ -263,7 +319,6 @@ RT_HD uint32_t rt_unorm8(float x) {
   if (c != c) c = 0.0f;
   return (uint32_t)rt_floor(c * 255.0f + 0.5f);
 }
-RT_HD float rt_from_unorm8(uint32_t q) { return (float)q / 255.0f; }
 
 /* f32 -> f16 bits, round to nearest even, overflow -> inf, NaN stays NaN. */
 RT_HD uint16_t rt_f32_to_f16(float f) {

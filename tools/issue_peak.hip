@@ -5,7 +5,11 @@
 // (DESIGN.md 4.1c); this tool gives that bound a measured denominator.
 //
 // Each kernel runs `iters` x 32 instructions per wave, 256-thread workgroups (one wave per SIMD each), W workgroups per CU.
-// Printed: wave-instructions per cycle per SIMD (clock from s_memtime / s_memrealtime).
+// Printed: wave-instructions per cycle per SIMD, TWICE: from the per-workgroup s_memtime spans (round 3's only figure) and
+// from the WALL CLOCK of the launch (hipEvent; launches of >= 10 ms) at the clock measured in the kernel.  Round 3's
+// launches lasted 0.5-1.5 ms and the workgroups of a launch do not run all at once when W x CUs exceeds what is resident
+// together with ramp-up, so the span-derived figure over-states the rate; the wall-clock figure is the one bench.py uses
+// and the one tools/valu_peak.hip agrees with.
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o issue_peak tools/issue_peak.hip      run: ./issue_peak
 #include <hip/hip_runtime.h>
@@ -72,11 +76,11 @@ int main() {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  printf("%-22s %-10s %26s %12s\n", "stream", "waves/SIMD", "wave-instr / cycle / SIMD", "clock GHz");
+  printf("%-22s %-10s %20s %20s %12s %10s %16s\n", "stream", "waves/SIMD", "instr/cyc/SIMD (span)", "instr/cyc/SIMD (wall)", "clock GHz", "ms", "T lane-instr/s");
   const char* names[3] = {"v_add_f32", "s_add_u32", "v_add_f32 : s_add_u32"};
   for (int kind = 0; kind < 3; kind++) {
     for (int waves : {1, 2, 4, 5, 6, 8}) {
-      const int iters = 20000, grid = cus * waves;
+      const int iters = 400000, grid = cus * waves;   // 12.8 M instructions per wave: >= 10 ms per launch
       float ms = 0.f;
       for (int rep = 0; rep < 2; rep++) {
         CHECK(hipEventRecord(e0));
@@ -95,7 +99,13 @@ int main() {
       }
       clk /= grid;
       cyc /= grid;   // cycles one workgroup (= one wave per SIMD) needed for its iters x 32 instructions
-      printf("%-22s %-10d %26.3f %12.2f\n", names[kind], waves, (double)waves * iters * 32.0 / cyc, clk);
+      // wall clock: every SIMD of the chip holds `waves` waves, each issuing iters x 32 instructions, in `ms` at `clk` GHz
+      const double wall_cycles = (double)ms * 1e-3 * clk * 1e9;
+      const double wall_rate = (double)waves * iters * 32.0 / wall_cycles;
+      const double vec_share = kind == 0 ? 1.0 : (kind == 1 ? 0.0 : 0.5);
+      const double lane_rate = (double)grid * 256.0 * iters * 32.0 * vec_share / ((double)ms * 1e-3) / 1e12;
+      printf("%-22s %-10d %20.3f %20.3f %12.2f %10.2f %16.2f\n", names[kind], waves, (double)waves * iters * 32.0 / cyc, wall_rate, clk, ms,
+             lane_rate);
       fflush(stdout);
     }
   }

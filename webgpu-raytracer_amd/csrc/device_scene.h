@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include "../../include/mi355rt_layout.h"
+#include "k_ieee.hip.h"   // before the math header: the device build's correctly rounded rcp / div / sqrt sequences
 #include "../../include/mi355rt_math.h"
 
 // 16-byte slots per triangle record.  4 (one aligned 64-byte line per triangle; a 48-byte record straddles two lines

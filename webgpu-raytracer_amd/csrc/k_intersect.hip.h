@@ -13,7 +13,7 @@ __device__ __forceinline__ LocalRay make_ray(rt3 o, rt3 d) {  // :83-86
   LocalRay r;
   r.o = o;
   r.d = d;
-  r.inv_d = rt3_splat(1.0f) / d;
+  r.inv_d = rt_rcp3(d);
   r.o_inv_d = o * r.inv_d;
   return r;
 }
@@ -35,7 +35,7 @@ __device__ __forceinline__ float hit_tri(float4 g0, float4 g1, float4 g2, const 
   rt3 h = rt_cross(r.d, e2);
   float a = rt_dot(e1, h);
   if (rt_abs(a) < 1e-6f) return -1.0f;
-  float f = 1.0f / a;
+  float f = rt_rcp(a);
   rt3 s = r.o - v0;
   float u = f * rt_dot(s, h);
   if (u < 0.0f || u > 1.0f) return -1.0f;

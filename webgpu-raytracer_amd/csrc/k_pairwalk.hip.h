@@ -59,7 +59,7 @@ RT_HD PwRay pw_make_ray(rt3 o, rt3 d) {  // make_ray, Raytracer.wgsl:83-86
   PwRay r;
   r.o = o;
   r.d = d;
-  r.inv_d = rt3_splat(1.0f) / d;
+  r.inv_d = rt_rcp3(d);
   r.o_inv_d = o * r.inv_d;
   return r;
 }

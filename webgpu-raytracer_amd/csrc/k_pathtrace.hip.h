@@ -72,17 +72,17 @@ __device__ rt3 ray_color(const DevScene& S, const DevFrame& F, const rt_scene_un
           rt3 bsdf_val = rt3_splat(0.0f);
           float bsdf_pdf = 0.0f;
           if (mat_type == 0u) {
-            bsdf_val = albedo / RT_PI;
-            bsdf_pdf = rt_max(rt_dot(normal, ls.dir), 0.0f) / RT_PI;
+            bsdf_val = rt_div_pi3(albedo);
+            bsdf_pdf = rt_div_pi(rt_max(rt_dot(normal, ls.dir), 0.0f));
           } else if (mat_type == 1u) {
             bsdf_val = eval_ggx(normal, -rd, ls.dir, roughness, f0);
             rt3 H = rt_normalize(-rd + ls.dir);
-            bsdf_pdf = (ggx_d(rt_dot(normal, H), roughness * roughness) * rt_max(rt_dot(normal, H), 0.0f)) /
-                       (4.0f * rt_max(rt_dot(-rd, H), 0.0f));
+            bsdf_pdf = rt_div(ggx_d(rt_dot(normal, H), roughness * roughness) * rt_max(rt_dot(normal, H), 0.0f),
+                              4.0f * rt_max(rt_dot(-rd, H), 0.0f));
           }
           if (bsdf_pdf > 0.0f) {
-            radiance = radiance + throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
-                                      rt_max(rt_dot(normal, ls.dir), 0.0f) / ls.pdf;
+            radiance = radiance + rt_div3z(throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                                               rt_max(rt_dot(normal, ls.dir), 0.0f), ls.pdf);
           }
         }
       }
@@ -112,7 +112,7 @@ __device__ rt3 ray_color(const DevScene& S, const DevFrame& F, const rt_scene_un
     if (depth > 3u) {  // Russian roulette
       float p = rt_max(throughput.x, rt_max(throughput.y, throughput.z));
       if (rand_pcg(rng) > p) break;
-      throughput = throughput / p;
+      throughput = rt_div3z(throughput, p);
     }
 
     if (depth < F.max_depth - 1u) {
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(64) void k_pathtrace(DevScene S, DevFrame F, rt_sce
         rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
         off = cu * rdk.x + cv * rdk.y;
       }
-      float u = ((float)x + 0.5f + U.jitter[0] * (float)U.width) / (float)U.width;
-      float v = 1.0f - ((float)y + 0.5f + U.jitter[1] * (float)U.height) / (float)U.height;
+      float u = rt_div((float)x + 0.5f + U.jitter[0] * (float)U.width, (float)U.width);
+      float v = 1.0f - rt_div((float)y + 0.5f + U.jitter[1] * (float)U.height, (float)U.height);
       rt3 d = cam_ll + u * cam_h + v * cam_v - cam_o - off;
       col = col + ray_color<DETAIL>(S, F, U, cam_o + off, d, rng, p_idx, c);
     }
-    col = col / (float)F.spp;
+    if (F.spp != 1u) col = rt_div3z(col, (float)F.spp);   // x / 1 = x
     float4 acc = make_float4(col.x, col.y, col.z, 1.0f);
     if (U.frame_count > 1u) {
       float4 prev = F.accum[p_idx];
@@ -300,13 +300,13 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
         rt3 bsdf_val = rt3_splat(0.0f);
         float bsdf_pdf = 0.0f;
         if (mat_type == 0u) {
-          bsdf_val = p.albedo / RT_PI;
-          bsdf_pdf = rt_max(rt_dot(p.normal, ls.dir), 0.0f) / RT_PI;
+          bsdf_val = rt_div_pi3(p.albedo);
+          bsdf_pdf = rt_div_pi(rt_max(rt_dot(p.normal, ls.dir), 0.0f));
         } else if (mat_type == 1u) {
           bsdf_val = eval_ggx(p.normal, -p.rd, ls.dir, roughness, f0);
           rt3 H = rt_normalize(-p.rd + ls.dir);
-          bsdf_pdf = (ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f)) /
-                     (4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
+          bsdf_pdf = rt_div(ggx_d(rt_dot(p.normal, H), roughness * roughness) * rt_max(rt_dot(p.normal, H), 0.0f),
+                            4.0f * rt_max(rt_dot(-p.rd, H), 0.0f));
         }
         o.want_shadow = true;  // the reference traces the shadow ray before looking at bsdf_pdf
         o.sh_o = hit_p + p.geom_n * 1e-4f;
@@ -314,8 +314,8 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
         o.sh_tmax = ls.dist - 2e-4f;
         o.nee_valid = bsdf_pdf > 0.0f;
         if (o.nee_valid) {
-          o.nee = p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
-                rt_max(rt_dot(p.normal, ls.dir), 0.0f) / ls.pdf;
+          o.nee = rt_div3z(p.throughput * bsdf_val * ls.L * power_heuristic(ls.pdf, bsdf_pdf) *
+                               rt_max(rt_dot(p.normal, ls.dir), 0.0f), ls.pdf);
         }
       }
     }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void shade_bounce(const DevScene& S, uint32_t light_c
         if (rand_pcg(p.rng) > pr) {
           ended = true;
         } else {
-          p.throughput = p.throughput / pr;
+          p.throughput = rt_div3z(p.throughput, pr);
         }
       }
       if (!ended) {
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
       }
     }
     // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
+    RT_LSTAT(6, !alive && have_pixel);
     if (!alive && have_pixel) {
       const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
       const DevFrameSlot slot = slots[item_slot];
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
         rt3 cv = rt3_make(U.camera.v[0], U.camera.v[1], U.camera.v[2]);
         off = cu * rdk.x + cv * rdk.y;
       }
-      float u = ((float)x + 0.5f + slot.jitter_x * (float)U.width) / (float)U.width;
-      float v = 1.0f - ((float)y + 0.5f + slot.jitter_y * (float)U.height) / (float)U.height;
+      float u = rt_div((float)x + 0.5f + slot.jitter_x * (float)U.width, (float)U.width);
+      float v = 1.0f - rt_div((float)y + 0.5f + slot.jitter_y * (float)U.height, (float)U.height);
       p.rd = cam_ll + u * cam_h + v * cam_v - cam_o - off;
       p.ro = cam_o + off;
       p.throughput = rt3_splat(1.0f);
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
     bool nee_valid = false;
     rt3 sh_o = rt3_splat(0.0f), sh_d = rt3_splat(0.0f), nee = rt3_splat(0.0f);
     float sh_tmax = 0.0f;
+    RT_LSTAT(0, running);
     if (running) {
       if (DETAIL) cnt_shaded++;
       BounceOut bo;
@@ -658,6 +660,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
       bool any_;
       traverse<false, DETAIL, MODE>(M, s_scene, WW, U.blas_base_idx, want_extend, p.ro, p.rd, RT_T_MAX, t_, tri_,
                                     inst_, any_, cnt_nodes, cnt_tris);
+      RT_LSTAT(5, want_extend && inst_ >= 0);
       if (want_extend) {
         cnt_ext++;
         if (inst_ < 0) {
@@ -677,12 +680,14 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
     const unsigned long long ps4 = __builtin_amdgcn_s_memtime();
 #endif
     // ------------------------------------------------------------ sample / pixel finished
+    RT_LSTAT(7, path_done);
     if (path_done) {
       alive = false;
       p.col = p.col + p.radiance;
       p.sample++;
       if (p.sample >= F.spp) {  // the item's last sample: Raytracer.wgsl:811-818
-        rt3 c = p.col / (float)F.spp;
+        rt3 c = p.col;
+        if (F.spp != 1u) c = rt_div3z(p.col, (float)F.spp);   // x / 1 = x, bit for bit
         if (F.frame_col) {
           // batched: park the frame colour; k_accumulate_frames adds the frames in order
           F.frame_col[(size_t)item_slot * ((size_t)U.width * U.height) + p.pixel] = make_float4(c.x, c.y, c.z, 1.0f);

@@ -28,7 +28,7 @@ __device__ __forceinline__ Bary barycentrics(const DevScene& S, uint32_t tri, rt
   b.e2 = xyz(S.tri_geom[RT_TRI_STRIDE * tri + 2]);
   rt3 s = lo - v0;
   rt3 h = rt_cross(ld, b.e2);
-  float f = 1.0f / rt_dot(b.e1, h);
+  float f = rt_rcp(rt_dot(b.e1, h));
   b.u = f * rt_dot(s, h);
   rt3 q = rt_cross(s, b.e1);
   b.v = f * rt_dot(ld, q);
@@ -38,7 +38,7 @@ __device__ __forceinline__ Bary barycentrics(const DevScene& S, uint32_t tri, rt
 }
 
 __device__ __forceinline__ rt2 pack_normal(rt3 n) {  // Rasterizer.wgsl:71-74
-  float s = 1.0f / (rt_abs(n.x) + rt_abs(n.y) + rt_abs(n.z));
+  float s = rt_rcp(rt_abs(n.x) + rt_abs(n.y) + rt_abs(n.z));
   rt2 p = rt2_make(n.x * s, n.y * s);
   if (n.z < 0.0f) {
     float ox = (1.0f - rt_abs(p.y)) * (p.x >= 0.0f ? 1.0f : -1.0f);
@@ -61,7 +61,7 @@ struct Onb {
 };
 __device__ __forceinline__ Onb build_onb(rt3 n) {  // :207-214
   float sign = (n.z >= 0.0f) ? 1.0f : -1.0f;
-  float a = -1.0f / (sign + n.z);
+  float a = -rt_rcp(sign + n.z);   // -1 / x = -(1 / x): negation is exact
   float b = n.x * n.y * a;
   Onb o;
   o.u = rt3_make(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
@@ -73,11 +73,11 @@ __device__ __forceinline__ rt3 to_world(const Onb& o, rt3 a) { return a.x * o.u 
 
 __device__ __forceinline__ float ggx_d(float n_dot_h, float a2) {  // :236-239
   float d = (n_dot_h * a2 - n_dot_h) * n_dot_h + 1.0f;
-  return a2 / (RT_PI * d * d);
+  return rt_div(a2, RT_PI * d * d);
 }
 __device__ __forceinline__ float ggx_g(float n_dot_v, float n_dot_l, float a2) {  // :241-245
-  float g1_v = 2.0f * n_dot_v / (n_dot_v + rt_sqrt(a2 + (1.0f - a2) * n_dot_v * n_dot_v));
-  float g1_l = 2.0f * n_dot_l / (n_dot_l + rt_sqrt(a2 + (1.0f - a2) * n_dot_l * n_dot_l));
+  float g1_v = rt_div(2.0f * n_dot_v, n_dot_v + rt_sqrt(a2 + (1.0f - a2) * n_dot_v * n_dot_v));
+  float g1_l = rt_div(2.0f * n_dot_l, n_dot_l + rt_sqrt(a2 + (1.0f - a2) * n_dot_l * n_dot_l));
   return g1_v * g1_l;
 }
 __device__ __forceinline__ float pow5(float x) {
@@ -118,7 +118,7 @@ __device__ Scatter sample_diffuse(rt3 normal, rt3 albedo, uint32_t& rng) {  // :
   Scatter s;
   s.dir = to_world(onb, rt3_make(cp * sin_theta, sp * sin_theta, cos_theta));
   float c = rt_max(rt_dot(normal, s.dir), 0.0f);
-  s.pdf = c / RT_PI;
+  s.pdf = rt_div_pi(c);
   s.throughput = albedo;
   s.specular = false;
   return s;
@@ -128,7 +128,7 @@ __device__ Scatter sample_ggx(rt3 n, rt3 v, float roughness, rt3 f0, uint32_t& r
   float ux = rand_pcg(rng);
   float uy = rand_pcg(rng);
   float phi = RT_TWO_PI * ux;
-  float cos_theta = rt_sqrt(rt_max(0.0f, (1.0f - uy) / (1.0f + (a * a - 1.0f) * uy)));
+  float cos_theta = rt_sqrt(rt_max(0.0f, rt_div(1.0f - uy, 1.0f + (a * a - 1.0f) * uy)));
   float sin_theta = rt_sqrt(rt_max(0.0f, 1.0f - cos_theta * cos_theta));
   float sp, cp;
   rt_sincos(phi, &sp, &cp);
@@ -152,7 +152,7 @@ __device__ Scatter sample_ggx(rt3 n, rt3 v, float roughness, rt3 f0, uint32_t& r
   float g = ggx_g(n_dot_v, n_dot_l, a2);
   rt3 f = fresnel_schlick(v_dot_h, f0);
   s.dir = l;
-  s.pdf = (d * n_dot_h) / (4.0f * v_dot_h);
+  s.pdf = rt_div(d * n_dot_h, 4.0f * v_dot_h);
   s.throughput = rt3_splat(0.0f);
   if (s.pdf > 1e-6f) s.throughput = (g * f * v_dot_h) / (n_dot_v * n_dot_h);
   s.specular = roughness < 0.01f;
@@ -160,7 +160,7 @@ __device__ Scatter sample_ggx(rt3 n, rt3 v, float roughness, rt3 f0, uint32_t& r
 }
 __device__ Scatter sample_dielectric(rt3 dir, rt3 normal, float ior, rt3 albedo, uint32_t& rng) {  // :320-339
   bool front_face = rt_dot(dir, normal) < 0.0f;
-  float ratio = front_face ? (1.0f / ior) : ior;
+  float ratio = front_face ? rt_rcp(ior) : ior;
   rt3 n = front_face ? normal : -normal;
   rt3 unit_dir = rt_normalize(dir);
   float cos_theta = rt_min(rt_dot(-unit_dir, n), 1.0f);
@@ -168,7 +168,7 @@ __device__ Scatter sample_dielectric(rt3 dir, rt3 normal, float ior, rt3 albedo,
   bool cannot_refract = ratio * sin_theta > 1.0f;
   bool reflect_it = cannot_refract;
   if (!reflect_it) {  // short-circuit `||`: the draw happens only when refraction is possible
-    float r0 = (1.0f - ratio) / (1.0f + ratio);
+    float r0 = rt_div(1.0f - ratio, 1.0f + ratio);
     r0 = r0 * r0;
     float refl = r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
     reflect_it = refl > rand_pcg(rng);
@@ -243,7 +243,7 @@ __device__ LightSample sample_light(const DevScene& S, uint32_t light_count, rt3
   s.L = L;
   s.dir = unit_l;
   s.dist = dist;
-  s.pdf = (dist_sq / (cos_l * area)) / (float)light_count;
+  s.pdf = rt_div(rt_div(dist_sq, cos_l * area), (float)light_count);
   return s;
 }
 __device__ float light_pdf(const DevScene& S, uint32_t light_count, uint32_t tri, uint32_t inst, float t,
@@ -257,11 +257,11 @@ __device__ float light_pdf(const DevScene& S, uint32_t light_count, uint32_t tri
   float cos_l = rt_max(rt_dot(normal, -l_dir), 0.0f);
   if (cos_l < 1e-4f) return 0.0f;
   float dist_sq = t * t;
-  return (dist_sq / (cos_l * area)) / (float)light_count;
+  return rt_div(rt_div(dist_sq, cos_l * area), (float)light_count);
 }
 __device__ __forceinline__ float power_heuristic(float a, float b) {
   float a2 = a * a, b2 = b * b;
-  return a2 / (a2 + b2);
+  return rt_div(a2, a2 + b2);
 }
 
 // ------------------------------------------------------------- counters

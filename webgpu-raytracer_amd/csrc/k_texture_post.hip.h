@@ -33,7 +33,7 @@ __device__ __forceinline__ rt3 pp_radiance(const DevPost& P, const rt_scene_unif
   int y = cy < 0 ? 0 : (cy > (int)U.height - 1 ? (int)U.height - 1 : cy);
   float4 a = P.accum[(size_t)y * U.width + (size_t)x];
   if (a.w <= 0.0f) return rt3_splat(0.0f);
-  return rt3_make(a.x, a.y, a.z) / a.w;
+  return rt_div3_plain(rt3_make(a.x, a.y, a.z), a.w);   // plain operators in this pass: zero numerators (black pixels) are the rule
 }
 // i32(floor(f)) for a texel coordinate, kept within +-2^30 so that the +-1 / tile-origin arithmetic that
 // follows cannot overflow (every coordinate is clamped to the image afterwards, so this changes no result;
@@ -68,7 +68,7 @@ __device__ __forceinline__ rt3 aces(rt3 color) {  // :36-39
   const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
   rt3 num = color * (a * color + rt3_splat(b));
   rt3 den = color * (c * color + rt3_splat(d)) + rt3_splat(e);
-  return rt_clamp3(num / den, rt3_splat(0.0f), rt3_splat(1.0f));
+  return rt_clamp3(rt3_make(num.x / den.x, num.y / den.y, num.z / den.z), rt3_splat(0.0f), rt3_splat(1.0f));
 }
 
 // k_postprocess: LDS-tiled.  A 16x16 block needs get_radiance_nearest on an 18x18 region; each of those
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void k_postprocess(DevPost P, rt_scene_uniform
       m1 = m1 + ncol;
       m2 = m2 + ncol * ncol;
     }
-  rt3 denoised = filtered_sum / rt_max(total_weight, 1e-4f);
+  rt3 denoised = rt_div3_plain(filtered_sum, rt_max(total_weight, 1e-4f));
 
   const size_t p_idx = (size_t)y * U.width + x;
   ushort4 hp = P.history_in[p_idx];
   rt3 hist = rt3_make(rt_f16_to_f32(hp.x), rt_f16_to_f32(hp.y), rt_f16_to_f32(hp.z));
-  rt3 mean = m1 / 9.0f;
-  rt3 var = rt_max3(m2 / 9.0f - mean * mean, rt3_splat(0.0f));
+  rt3 mean = rt_div3_plain(m1, 9.0f);
+  rt3 var = rt_max3(rt_div3_plain(m2, 9.0f) - mean * mean, rt3_splat(0.0f));
   rt3 stddev = rt3_make(rt_sqrt(var.x), rt_sqrt(var.y), rt_sqrt(var.z));
   float k = (U.frame_count > 16u) ? 60.0f : 1.0f;
   rt3 clamped = rt_clamp3(hist, mean - stddev * k, mean + stddev * k);

@@ -102,7 +102,7 @@ __device__ __forceinline__ bool hit_tri_nb(f4 g0, f4 g1, f4 g2, const LocalRay& 
   rt3 v0 = rt3_make(g0.x, g0.y, g0.z), e1 = rt3_make(g1.x, g1.y, g1.z), e2 = rt3_make(g2.x, g2.y, g2.z);
   rt3 h = rt_cross(r.d, e2);
   float a = rt_dot(e1, h);
-  float f = 1.0f / a;
+  float f = rt_rcp(a);
   rt3 s = r.o - v0;
   float u = f * rt_dot(s, h);
   rt3 q = rt_cross(s, e1);
@@ -153,6 +153,24 @@ __device__ __forceinline__ void wave_work_at(WaveWork& W, char* wbase) {
                             // (fewer = partial 64-item chunks, more = lanes wait longer for their results)
 #endif
 
+// Diagnostic build only (-DRT_LANE_STATS, tools/lane_stats.py): how many lanes are active each time a wave executes one of
+// the parts of a trip — g_lane_stats[2 k] = times part k ran, [2 k + 1] = active lanes summed.  Parts: 0 shade, 1 / 2 node step
+// and triangle chunk of the shadow walk, 3 / 4 the same of the extension walk, 5 surface frame of the new hit, 6 start of a
+// sample (camera ray + G-buffer surface), 7 end of a sample.  Nothing else reads the array; in the product build RT_LSTAT is empty.
+__device__ unsigned long long g_lane_stats[32];
+#ifdef RT_LANE_STATS
+#define RT_LSTAT(k, cond)                                                                                  \
+  do {                                                                                                     \
+    const unsigned long long m_ = __ballot(cond);                                                          \
+    if (m_ != 0ull && (threadIdx.x & 63u) == 0u) {                                                         \
+      atomicAdd(&g_lane_stats[2 * (k)], 1ull);                                                             \
+      atomicAdd(&g_lane_stats[2 * (k) + 1], (unsigned long long)__builtin_popcountll(m_));                 \
+    }                                                                                                      \
+  } while (0)
+#else
+#define RT_LSTAT(k, cond) ((void)0)
+#endif
+
 struct Trav {  // one ray's traversal state
   LocalRay r;                // the ray in the space it is currently walking (world or instance)
   LocalRay rw;               // the world-space ray (rw.o, rw.d = the ray as given)
@@ -161,6 +179,9 @@ struct Trav {  // one ray's traversal state
   uint32_t curr, tlas_next, cur_inst, leaf;
   bool searching, waiting, in_blas, any;
   bool entering;             // mixed mode: hit a TLAS leaf, instance entry pending (still `searching`)
+#ifdef RT_LANE_STATS
+  uint32_t stat_kind;        // 1 = shadow walk, 3 = extension walk (RT_LSTAT part of its node steps; + 1 = its triangle chunks)
+#endif
 };
 
 __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_max) {
@@ -178,6 +199,9 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
   s.in_blas = false;
   s.any = false;
   s.entering = false;
+#ifdef RT_LANE_STATS
+  s.stat_kind = 1u;
+#endif
 }
 
 // the walk ran off its array (rare): leave the instance (back to the world-space ray and the TLAS cursor), or finish.
@@ -246,6 +270,9 @@ __device__ __forceinline__ void trav_node(const TravMem& M, const f4* lds, Trav&
 template <bool COUNT, int MODE>
 __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
   trav_leave(s);
+#ifdef RT_LANE_STATS
+  RT_LSTAT(s.stat_kind, s.searching);
+#endif
   if (s.searching) {
     f4 lo, hi;
     trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
@@ -365,6 +392,9 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
   const bool tri_lds = MODE == RT_TRAV_LDS || M.l_tri != RT_LDS_NONE;   // wave-uniform
   for (uint32_t c = 0; c < total; c += 64u) {
     const uint32_t j = c + lane;
+#ifdef RT_LANE_STATS
+    RT_LSTAT(s.stat_kind + 1u, j < total);
+#endif
     if (j < total) {
       const uint32_t it = W.items[j];
       const uint32_t owner = it >> 26, tri = it & 0x03ffffffu;
@@ -419,6 +449,9 @@ __device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const 
                                          int32_t& out_inst, bool& out_any, uint32_t& n_nodes, uint32_t& n_tris) {
   Trav s;
   trav_begin(s, active, blas_base, o, d, t_max);
+#ifdef RT_LANE_STATS
+  s.stat_kind = ANY ? 1u : 3u;
+#endif
   for (;;) {
     // RT_STEPS_PER_TRIP node steps between two looks at the triangle queue: the look (ballots, population counts, the
     // branch) costs a third of a trip; a lane that reaches a leaf in an earlier step simply sits out the later ones

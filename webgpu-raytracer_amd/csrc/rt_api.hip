@@ -25,6 +25,7 @@
 #include "kernels.hip.h"
 #include "bvh_build.hip.h"
 #include "world_update.hip.h"
+#include "k_ieee_check.hip.h"
 
 namespace {
 
@@ -621,7 +622,11 @@ int rt_set_pipeline(rt_ctx* c, uint32_t max_depth, uint32_t spp) {
 
 int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   if (!c) return RT_ERR_INVALID;
-  c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
+  c->epoch++;   // drops frames traced ahead (rt_set_lookahead) ...
+  // ... and what rt_read_gbuffer remembers of them: their planes are freed / sized for the old screen below
+  c->gbuf_slot = -1;
+  c->spec.valid = false;
+  c->spec.slots.clear();
   if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
     return fail(c, RT_ERR_INVALID, "invalid screen size");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1726,8 +1731,6 @@ static int compute_frames(rt_ctx* c, const uint32_t* frame_counts, uint32_t n, u
     if (i + 1 == n_commit) committed = {c->total_frames, c->jx, c->jy, c->acc_jx, c->acc_jy, c->avg_jx, c->avg_jy, c->uniforms};
   }
   // the renderer's host state is that of the committed frames only
-  const rt_scene_uniforms launch_uniforms = c->uniforms;
-  (void)launch_uniforms;
   c->total_frames = committed.total_frames;
   c->jx = committed.jx; c->jy = committed.jy;
   c->acc_jx = committed.acc_jx; c->acc_jy = committed.acc_jy;
@@ -2047,7 +2050,9 @@ int rt_read_gbuffer(rt_ctx* c, uint8_t* albedo, float* normal_id, float* depth) 
   const size_t n = (size_t)c->width * c->height;
   HIP_TRY(c, hipSetDevice(c->device));
   const void *pa = c->render_target.ptr, *pn = c->g_normal.ptr, *pd = c->g_depth.ptr;
-  if (c->gbuf_slot >= 0 && (size_t)c->gbuf_slot < c->spec.slots.size()) {   // the frame of the last compute() was traced as part of a batch
+  // the frame of the last compute() was traced as part of a batch; rt_resize and the next dispatch (the only calls that free
+  // or reuse the batch's planes) reset gbuf_slot
+  if (c->gbuf_slot >= 0 && (size_t)c->gbuf_slot < c->spec.slots.size()) {
     const DevFrameSlot& sl = c->spec.slots[c->gbuf_slot];
     pa = sl.albedo;
     pn = sl.normal_id;
@@ -2218,6 +2223,21 @@ int rt_debug_pt_sections(rt_ctx* c, uint64_t* out8, int reset) {
   return 0;
 #endif
 }
+int rt_debug_lane_stats(rt_ctx* c, uint64_t* out32, int reset) {
+  if (!c || !out32) return RT_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(rtk::g_lane_stats), 256, 0, hipMemcpyDeviceToHost));
+  if (reset) {
+    uint64_t zero[32] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_lane_stats), zero, 256, 0, hipMemcpyHostToDevice));
+  }
+#ifdef RT_LANE_STATS
+  return 1;
+#else
+  return 0;
+#endif
+}
 int rt_debug_clock_stamps(rt_ctx* c, uint64_t* out_pairs, uint32_t cap_pairs) {
   if (!c || !out_pairs) return RT_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2228,6 +2248,42 @@ int rt_debug_clock_stamps(rt_ctx* c, uint64_t* out_pairs, uint32_t cap_pairs) {
   return (int)n;
 #else
   return 0;  // product build: the kernels execute no stamp
+#endif
+}
+int rt_debug_ieee_check(rt_ctx* c, int op, uint64_t first, uint64_t count, rt_ieee_report* out) {
+  if (!c || !out) return RT_ERR_INVALID;
+  static_assert(sizeof(rt_ieee_report) == sizeof(rtk::IeeeReport), "report layouts differ");
+  std::memset(out, 0, sizeof(*out));
+#ifdef RT_IEEE_PLAIN
+  return fail(c, RT_ERR_INVALID, "rt_debug_ieee_check: built with RT_IEEE_PLAIN, the kernels use the plain operators");
+#else
+  if (op < 0 || op >= RT_IEEE_OP_COUNT) return fail(c, RT_ERR_INVALID, "rt_debug_ieee_check: unknown op");
+  if (count == 0) return RT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  rtk::IeeeReport* d = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d, sizeof(rtk::IeeeReport)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(rtk::IeeeReport), c->stream);
+  const uint64_t want = (count + 255) / 256;
+  const dim3 grid((uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 32u)), block(256);
+  if (e == hipSuccess) {
+    switch (op) {
+      case RT_IEEE_OP_RCP: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_RCP>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_SQRT: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_SQRT>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_RSQRT: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_RSQRT>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_DIV: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_DIV>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_DIV3: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_DIV3>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_DIV3Z: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_DIV3Z>, grid, block, 0, c->stream, first, count, d); break;
+      case RT_IEEE_OP_DIV_PI: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_DIV_PI>, grid, block, 0, c->stream, first, count, d); break;
+      default: hipLaunchKernelGGL(rtk::k_ieee_check<RT_IEEE_OP_UNORM8>, grid, block, 0, c->stream, first, count, d); break;
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(*out), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return hip_fail(c, e, "rt_debug_ieee_check");
+  out->n = count;
+  return RT_OK;
 #endif
 }
 int rt_kernel_times(rt_ctx* c, double* sum_ms, uint32_t* launches, uint32_t n) {

@@ -166,9 +166,10 @@ def load_library(path=None):
         "rt_reset_counters": (i32, [vp]), "rt_set_counting": (i32, [vp, i32]),
         "rt_set_stripes": (i32, [vp, u32, u32, u32]), "rt_accum_device_ptr": (vp, [vp]),
         "rt_set_stream": (i32, [vp, vp]), "rt_bind_present_source": (i32, [vp, vp]),
-        "rt_debug_clock_stamps": (i32, [vp, vp, u32]), "rt_debug_trace_sections": (i32, [vp, vp, i32]), "rt_debug_pt_sections": (i32, [vp, vp, i32]),
+        "rt_debug_clock_stamps": (i32, [vp, vp, u32]), "rt_debug_trace_sections": (i32, [vp, vp, i32]), "rt_debug_pt_sections": (i32, [vp, vp, i32]), "rt_debug_lane_stats": (i32, [vp, vp, i32]),
         "rt_debug_read_traversal_nodes": (i32, [vp, vp, vp, vp, u32]),
         "rt_debug_read_pairs": (i32, [vp, vp, vp, u32]),
+        "rt_debug_ieee_check": (i32, [vp, i32, ctypes.c_uint64, ctypes.c_uint64, vp]),
         "rt_kernel_times": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32), u32]),
         "rt_kernel_time_ms": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(u32)]),
@@ -193,7 +194,7 @@ EXPORTED_SYMBOLS = (
     "rt_alloc_texture_layers rt_upload_texture_image rt_read_texture_layer rt_build_blas "
     "rt_upload_geometry rt_upload_bvh rt_set_scene rt_recreate_bind_group rt_compute rt_compute_batch rt_present rt_capture "
     "rt_sync rt_read_accum rt_write_accum rt_read_gbuffer rt_read_history rt_read_uniforms rt_get_counters "
-    "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_read_traversal_nodes rt_debug_read_pairs "
+    "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_lane_stats rt_debug_read_traversal_nodes rt_debug_read_pairs rt_debug_ieee_check "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead "
     "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit rt_world_set_static_cache").split()
