@@ -84,6 +84,12 @@ int ms_world_device_resident(const ms_world* w);
  * worked out by hand from the Rust source. */
 int ms_build_blas(const float* verts4, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, float* nodes_out,
                   uint32_t nodes_cap, uint32_t* n_nodes_out, uint32_t* order_out);
+/* The CPU TLAS builder alone: TLASBuilder::new + build of bvh/tlas.rs:17-111 on n instances given by their BLAS root
+ * boxes (6 f32: min.xyz, max.xyz, object space) and transforms (16 f32 column-major each; NULL = identity) -> 8 f32 per
+ * node and the instance order (sorted_instances[k] = instance order_out[k]).  0 on success, -1 on a bad argument.
+ * tests/test_bvh_independent.py pins it with node arrays worked out by hand from the Rust source. */
+int ms_build_tlas(const float* boxes6, const float* transforms16, uint32_t n, float* nodes_out, uint32_t nodes_cap,
+                  uint32_t* n_nodes_out, uint32_t* order_out);
 /* World::update_camera(width, height) lib.rs:347-352. */
 void ms_world_update_camera(ms_world* w, float width, float height);
 

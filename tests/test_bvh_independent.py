@@ -2,7 +2,9 @@
 
  (a) known-answer node arrays WORKED OUT BY HAND from /root/reference/rust-shader-tools/src/bvh/blas.rs:87-217 (bins, SAH
      costs, two-pointer partition, child rotation) for two small meshes with binary-exact coordinates; the derivations
-     are in the docstrings, the expected arrays in tests/golden/blas_kat.json;
+     are in the docstrings, the expected arrays in tests/golden/blas_kat.json; the same for the TLAS builder
+     (bvh/tlas.rs:58-111: axis rule, STABLE sort, costlier half first; tests/golden/tlas_kat.json), checked against the CPU
+     builder here and against the device kernel k_tlas in tests/test_gpu_world_update.py;
  (b) structural validity of every scene's TLAS / BLAS arrays: every triangle of a geometry sits in exactly one leaf of its
      BLAS, every node box encloses what is below it, skip pointers describe a pre-order tree;
  (c) ray queries: the restated stackless traversal over those arrays against brute force over every (instance, triangle)
@@ -19,6 +21,7 @@ import parity_util as pu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KAT = json.load(open(os.path.join(REPO, "tests", "golden", "blas_kat.json")))
+TLAS_KAT = json.load(open(os.path.join(REPO, "tests", "golden", "tlas_kat.json")))
 
 
 def cpu_build_blas(W, verts, tris):
@@ -258,3 +261,91 @@ def test_traversal_finds_the_brute_force_closest_hit(W, oracle_lib, scene, n_ray
         missed = diff & (bvh[:, 1] < 0)
         rel = np.abs(bvh[diff & ~missed, 0] - brute[diff & ~missed, 0]) / brute[diff & ~missed, 0]
         assert (rel < 1e-4).all() and missed.sum() <= max(2, n_rays // 20000)
+
+
+# ------------------------------------------------------------------------------------------------ TLAS known answers
+def cpu_build_tlas(W, boxes, translations=None):
+    lib = ctypes.CDLL(W._build.build_scene())
+    n = len(boxes)
+    b6 = np.ascontiguousarray(np.asarray(boxes, np.float32).reshape(n, 6))
+    xf = None
+    if translations is not None:
+        xf = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (n, 1))
+        xf[:, 12:15] = np.asarray(translations, np.float32)          # column-major: column 3 = translation
+    nodes = np.zeros((2 * n, 8), np.float32)
+    order = np.zeros(n, np.uint32)
+    n_nodes = ctypes.c_uint32()
+    vp = ctypes.c_void_p
+    lib.ms_build_tlas.argtypes = [vp, vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), vp]
+    rc = lib.ms_build_tlas(b6.ctypes.data_as(vp), xf.ctypes.data_as(vp) if xf is not None else None, n, nodes.ctypes.data_as(vp),
+                           nodes.shape[0], ctypes.byref(n_nodes), order.ctypes.data_as(vp))
+    assert rc == 0
+    nodes = nodes[:n_nodes.value]
+    u = nodes.view(np.uint32)
+    return [{"min": nodes[i, 0:3].tolist(), "skip": int(u[i, 3]), "max": nodes[i, 4:7].tolist(), "data": int(u[i, 7])}
+            for i in range(len(nodes))], order.tolist()
+
+
+def test_tlas_known_answer_axis_rule_is_not_longest_axis(W):
+    """Four instances, all x in [0, 2]: I0 y[0,1] z[0,1], I1 y[0,1] z[7,8], I2 y[2,3] z[3,4], I3 y[2,3] z[5,6].
+
+    subdivide(0, 4) (tlas.rs:58): node 0 box = [0,2] x [0,3] x [0,8] (:62-67), extent (2, 3, 8).  tlas.rs:76:
+    `extent.y > extent.x` is TRUE -> axis 1, although z is the longest axis.  Centres (box min + max) * 0.5 (primitives.rs:52):
+    y = 0.5, 0.5, 2.5, 2.5 -> the (stable) sort leaves [0,1,2,3] (:78-83).  mid = 2 (:85): left {I0,I1} = [0,2]x[0,1]x[0,8],
+    d = (2,1,8), area = 2 (2*1 + 1*8 + 8*2) = 52 (primitives.rs:41-50), cost 52 * 2 = 104; right {I2,I3} = [0,2]x[2,3]x[3,6],
+    d = (2,1,3), area 2 (2 + 3 + 6) = 22, cost 44.  44 > 104 is false -> no rotation (:98-103).
+    (A longest-axis builder sorts by z: 0.5, 7.5, 3.5, 5.5 -> [0,2,3,1], halves {I0,I2} / {I3,I1}: another tree.)
+      node 1 = subdivide(0,2): [0,2]x[0,1]x[0,8], extent (2,1,8): y > x false; z > x and z > y -> axis 2; z centres 0.5, 7.5 ->
+               [0,1]; both halves area 2 (2+1+2) = 10 -> no rotation.  node 2 = leaf I0: data (0 << 3) | 1 = 1, skip 3 (:69-73);
+               node 3 = leaf I1: data (1 << 3) | 1 = 9, skip 4; node 1 skip 4 (:110).
+      node 4 = subdivide(2,2): [0,2]x[2,3]x[3,6], extent (2,1,3) -> axis 2; 3.5, 5.5 -> [2,3]; 10 vs 10.  node 5 = leaf I2:
+               data (2 << 3) | 1 = 17, skip 6; node 6 = leaf I3: data 25, skip 7; node 4 skip 7; node 0 skip 7."""
+    k = TLAS_KAT["axis_rule"]
+    nodes, order = cpu_build_tlas(W, k["boxes"])
+    assert order == k["order"] == [0, 1, 2, 3]
+    assert nodes == k["nodes"]
+
+
+def test_tlas_known_answer_equal_centres_keep_their_order(W):
+    """Four instances, all y, z in [0, 1]: I0 x[3,5], I1 x[0,8], I2 x[2,6], I3 x[0,2]: centres x = 4, 4, 4, 1.
+
+    Root [0,8]x[0,1]x[0,1], extent (8,1,1): y > x false, z > x false -> axis 0.  slice.sort_by is a STABLE sort (tlas.rs:79):
+    I3 (1) first, then I0, I1, I2 in their original order: [3,0,1,2] (an unstable sort may permute the three ties and give
+    another tree).  mid = 2: left {I3,I0} = x[0,5], d (5,1,1), area 2 (5 + 1 + 5) = 22, cost 44; right {I1,I2} = x[0,8], area
+    2 (8 + 1 + 8) = 34, cost 68.  68 > 44 -> rotate_left(2) (:99): order [1,2,3,0], l_count = r_count = 2.
+      node 1 = subdivide(0,2): I1, I2: x[0,8], axis 0, centres 4, 4 -> [1,2] stays; left {I1} 34 * 1, right {I2} x[2,6] area
+               2 (4 + 1 + 4) = 18: 18 > 34 false.  node 2 = leaf I1 (data 1, skip 3), node 3 = leaf I2 (data 9, skip 4); skip 4.
+      node 4 = subdivide(2,2): I3, I0: x[0,5], axis 0, centres 1, 4 -> [3,0]; areas 10, 10.  node 5 = leaf I3 (data 17, skip 6),
+               node 6 = leaf I0 (data 25, skip 7); node 4 skip 7; node 0 skip 7."""
+    k = TLAS_KAT["stable_ties"]
+    nodes, order = cpu_build_tlas(W, k["boxes"])
+    assert order == k["order"] == [1, 2, 3, 0]
+    assert nodes == k["nodes"]
+
+
+def test_tlas_known_answer_costlier_half_goes_first(W):
+    """Three instances, x in [0,2]: I0 y[0,1] z[0,1], I1 y[2,3] z[3,4], I2 y[1,2] z[7,8].
+
+    Root [0,2]x[0,3]x[0,8], extent (2,3,8) -> axis 1 (y > x).  y centres 0.5, 2.5, 1.5 -> [0,2,1].  mid = 3 / 2 = 1: left {I0},
+    d (2,1,1), area 10, cost 10; right {I2,I1} = [0,2]x[1,3]x[3,8], d (2,2,5), area 2 (4 + 10 + 10) = 48, cost 96.  96 > 10 ->
+    rotate_left(1): [2,1,0], l_count = 2, r_count = 1: the costlier half becomes the FIRST child (:98-103).
+      node 1 = subdivide(0,2): I2, I1: extent (2,2,5): y > x is false (2 > 2), z > x and z > y -> axis 2; z centres 7.5, 3.5 ->
+               sorted [1,2], so the order is now [1,2,0]; areas 10, 10 -> no rotation.  node 2 = leaf I1 [0,2]x[2,3]x[3,4]
+               (data 1, skip 3), node 3 = leaf I2 [0,2]x[1,2]x[7,8] (data 9, skip 4); node 1 skip 4.
+      node 4 = subdivide(2,1): leaf I0: data (2 << 3) | 1 = 17, skip 5; node 0 skip 5."""
+    k = TLAS_KAT["costlier_half_first"]
+    nodes, order = cpu_build_tlas(W, k["boxes"])
+    assert order == k["order"] == [1, 2, 0]
+    assert nodes == k["nodes"]
+
+
+def test_tlas_known_answer_boxes_are_transformed(W):
+    """Two unit cubes, the first translated by (4,0,0) (AABB::transform of its 8 corners, primitives.rs:55-76, tlas.rs:24-27):
+    world boxes [4,5] and [0,1] on x.  Root [0,5]x[0,1]x[0,1] -> axis 0; centres 4.5, 0.5 -> [1,0]; areas 6, 6 -> no rotation.
+    node 1 = leaf I1 (data 1, skip 2), node 2 = leaf I0 (data 9, skip 3); and a single instance is one leaf with skip 1."""
+    k = TLAS_KAT["translated"]
+    nodes, order = cpu_build_tlas(W, k["boxes"], k["translations"])
+    assert order == k["order"] == [1, 0]
+    assert nodes == k["nodes"]
+    one, o1 = cpu_build_tlas(W, [[1, 2, 3, 4, 6, 8]])
+    assert o1 == [0] and one == [{"min": [1.0, 2.0, 3.0], "skip": 1, "max": [4.0, 6.0, 8.0], "data": 1}]

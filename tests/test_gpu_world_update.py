@@ -289,3 +289,57 @@ def test_device_updater_refuses_a_destroyed_renderer(W):
     b.setDeviceUpdater(None)
     b.update(0.1)
     assert not b.deviceResident
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["axis_rule", "stable_ties", "costlier_half_first", "translated"])
+def test_device_tlas_equals_the_hand_derived_arrays(W, case):
+    """k_tlas (csrc/world_update.hip.h) against the TLAS node arrays and instance orders worked out by hand from
+    bvh/tlas.rs:58-111 (tests/golden/tlas_kat.json; derivations in tests/test_bvh_independent.py, where the CPU builder is
+    held to the same arrays): the axis rule that is not "longest axis", the STABLE sort on equal centres, the costlier half
+    first, boxes of transformed instances.  rt_world_update is called directly with a hand-made frame: one geometry per
+    instance, a single triangle (x0,y0,z0) (x1,y1,z0) (x0,y0,z1) whose box is the instance's box."""
+    import ctypes
+    import json
+    import os
+    from test_world_device_hook import Frame, Geometry
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tlas_kat.json")))[case]
+    f32 = np.float32
+    fp, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)
+    keep, geos, rows = [], [], []
+    for gi, b in enumerate(kat["boxes"]):
+        x0, y0, z0, x1, y1, z1 = b
+        pos = np.array([[x0, y0, z0], [x1, y1, z0], [x0, y0, z1]], f32)
+        nrm = np.tile(np.array([0, 0, 1], f32), (3, 1))
+        joints, weights = np.zeros((3, 4), np.uint32), np.zeros((3, 4), f32)
+        idx, attr = np.array([0, 1, 2], np.uint32), np.full((1, 16), 0.5, f32)
+        keep += [pos, nrm, joints, weights, idx, attr]
+        g = Geometry()
+        g.positions, g.normals, g.uvs = pos.ctypes.data_as(fp), nrm.ctypes.data_as(fp), None
+        g.joints, g.weights = joints.ctypes.data_as(up), weights.ctypes.data_as(fp)
+        g.indices, g.attributes = idx.ctypes.data_as(up), attr.ctypes.data_as(fp)
+        g.n_verts, g.n_uvs, g.n_tris, g.skin = 3, 0, 1, -1
+        geos.append(g)
+        m = np.eye(4, dtype=f32)
+        if "translations" in kat:
+            m[:3, 3] = kat["translations"][gi]
+        row = np.zeros(36, f32)
+        row[:16] = m.T.reshape(-1)
+        row[16:32] = np.linalg.inv(m).T.reshape(-1).astype(f32)
+        row[32:].view(np.uint32)[:] = (0, 0, gi, 0)
+        rows.append(row)
+    inst = np.stack(rows)
+    arr = (Geometry * len(geos))(*geos)
+    fr = Frame()
+    fr.static_epoch, fr.n_geometries, fr.n_instances, fr.n_skins = 7001, len(geos), len(inst), 0
+    fr.geometries, fr.instances = arr, inst.ctypes.data_as(fp)
+    r = W.WebGPURenderer(0)
+    rc = r.L.rt_world_update(r.ctx, ctypes.byref(fr))
+    assert rc >= 0, r.L.rt_last_error(r.ctx).decode()
+    tlas = r.worldRead("tlas").reshape(-1, 8)
+    u = tlas.view(np.uint32)
+    got = [{"min": tlas[i, 0:3].tolist(), "skip": int(u[i, 3]), "max": tlas[i, 4:7].tolist(), "data": int(u[i, 7])} for i in range(len(tlas))]
+    assert got == kat["nodes"]
+    out_inst = r.worldRead("instances").reshape(-1, 36)
+    assert [int(v) for v in out_inst[:, 34].view(np.uint32)] == kat["order"]      # instance_id = the geometry = the input index
+    r.destroy()

@@ -1700,6 +1700,32 @@ int ms_build_blas(const float* verts4, uint32_t n_verts, const uint32_t* indices
   *n_nodes_out = (uint32_t)bb.nodes.size();
   return 0;
 }
+int ms_build_tlas(const float* boxes6, const float* transforms16, uint32_t n, float* nodes_out, uint32_t nodes_cap,
+                  uint32_t* n_nodes_out, uint32_t* order_out) {
+  if (!n_nodes_out) return -1;
+  *n_nodes_out = 0;
+  if (n == 0) return 0;
+  if (!boxes6 || !nodes_out || !order_out) return -1;
+  std::vector<RawInstance> inst(n);
+  std::vector<Aabb> boxes(n);
+  for (uint32_t i = 0; i < n; i++) {
+    boxes[i].mn = v3(boxes6[6 * i], boxes6[6 * i + 1], boxes6[6 * i + 2]);
+    boxes[i].mx = v3(boxes6[6 * i + 3], boxes6[6 * i + 4], boxes6[6 * i + 5]);
+    if (transforms16)
+      std::memcpy(&inst[i].transform, transforms16 + 16 * (size_t)i, 64);
+    else
+      inst[i].transform = m4_identity();
+  }
+  TlasBuilder tb(inst, boxes);
+  tb.build();
+  if (tb.nodes.size() > nodes_cap) return -1;
+  std::vector<float> packed;
+  pack_nodes(tb.nodes, packed);
+  std::memcpy(nodes_out, packed.data(), packed.size() * 4);
+  for (size_t i = 0; i < tb.order.size(); i++) order_out[i] = (uint32_t)tb.order[i];
+  *n_nodes_out = (uint32_t)tb.nodes.size();
+  return 0;
+}
 size_t ms_world_node_count(const ms_world* w) { return w ? w->gltf.nodes.size() : 0; }
 size_t ms_world_encoded_texture_count(const ms_world* w) { return w ? w->scene.textures.size() : 0; }
 const uint8_t* ms_world_encoded_texture(const ms_world* w, size_t index, size_t* size) {

@@ -52,7 +52,11 @@ class ShardedImage:
             self.stream = torch.cuda.Stream(device=self.device)   # a side stream: its handle is never 0 ("own stream")
         with torch.cuda.stream(self.stream):
             self.stripe = torch.zeros((r.height, r.width, 4), dtype=torch.float32, device=self.device)
-            self.display = torch.zeros((r.height, r.width, 4), dtype=torch.float32, device=self.device)
+            # the display buffer has world x max_rows rows: the image in the first `height`, then one scratch row per
+            # padding row of the gathered blocks, so that rank 0 unpacks ALL blocks with ONE index_copy_ (below)
+            self._display_ext = torch.zeros((max(r.height, self.world * self.max_rows(r.height)), r.width, 4),
+                                            dtype=torch.float32, device=self.device)
+            self.display = self._display_ext[:r.height]
         self._plan_key = None
         self.stream.synchronize()              # the zero fills are done before the renderer is pointed at the memory
         r.setStream(self.stream.cuda_stream)
@@ -89,26 +93,53 @@ class ShardedImage:
             self._own_idx = torch.from_numpy(self.rows_of(self.rank, h)).to(self.device)
             self._send = torch.zeros((mr, w, 4), dtype=torch.float32, device=self.device)
             if self.rank == 0:
-                self._recv = [torch.zeros((mr, w, 4), dtype=torch.float32, device=self.device) for _ in range(self.world)]
-                self._idx = [torch.from_numpy(self.rows_of(k, h)).to(self.device) for k in range(self.world)]
+                # one receive buffer, rank k's block at [k]; row j of block k goes to image row rows_of(k)[j], a padding
+                # row (j >= the rank's row count) to a scratch row of its own behind the image
+                self._recv_all = torch.zeros((self.world, mr, w, 4), dtype=torch.float32, device=self.device)
+                self._recv = [self._recv_all[k] for k in range(self.world)]
+                dst, scratch = [], h
+                for k in range(self.world):
+                    rk = self.rows_of(k, h)
+                    dst += list(rk) + list(range(scratch, scratch + mr - len(rk)))
+                    scratch += mr - len(rk)
+                self._dst_rows = torch.tensor(dst, dtype=torch.int64, device=self.device)
             else:
-                self._recv = self._idx = None
+                self._recv_all = self._recv = self._dst_rows = None
         self._plan_key = key
         self.collective_ms = 0.0
         self._coll_events = []
 
     # ------------------------------------------------------------------ render / gather
-    def render(self, frames, batch=1):
+    def render(self, frames, batch=1, timed=False):
         """Same per-frame call as the live loop, but present() is deferred to gather(). batch > 1 issues the
         frames as batched dispatches (rt_compute_batch, like the recorder's batch loop): bit-identical, and each
-        launch carries `batch` times the work, which is what keeps a GPU busy on 1/N of an image."""
+        launch carries `batch` times the work, which is what keeps a GPU busy on 1/N of an image.  timed (device path):
+        events around this rank's dispatches on the stream (render_time_ms() reads them: the per-rank load balance)."""
         frames = list(frames)
+        ev = None
+        if timed and self.stream is not None:
+            import torch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.stream)
         if batch > 1 and hasattr(self.r, "computeBatch"):
             for i in range(0, len(frames), batch):
                 self.r.computeBatch(frames[i:i + batch])
         else:
             for f in frames:
                 self.r.compute(f)
+        if ev is not None:
+            ev[1].record(self.stream)
+            self.__dict__.setdefault("_render_events", []).append(ev)
+
+    def render_time_ms(self):
+        """Sum of the timed render() calls' stream durations on THIS rank since the last call, and their count."""
+        ev = self.__dict__.get("_render_events", [])
+        if not ev:
+            return 0.0, 0
+        self.stream.synchronize()
+        ms, n = sum(a.elapsed_time(b) for a, b in ev), len(ev)
+        self._render_events = []
+        return ms, n
 
     def gather(self, present=True, timed=False):
         """Assemble the image on rank 0 from the ranks' compact stripes (one gather); rank 0 then runs the post pass on
@@ -123,17 +154,20 @@ class ShardedImage:
                     # renderer kernels, the packing copy, the collective and the unpacking copies are ordered by the one
                     # side stream: no host synchronisation anywhere
                     if timed:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                         e0.record(self.stream)
                     n_own = self._own_idx.numel()
                     torch.index_select(self.stripe, 0, self._own_idx, out=self._send[:n_own])
                     dist.gather(self._send, gather_list=self._recv, dst=0)
-                    if self.rank == 0:
-                        for k in range(self.world):
-                            self.display.index_copy_(0, self._idx[k], self._recv[k][:self._idx[k].numel()])
                     if timed:
                         e1.record(self.stream)
-                        self._coll_events.append((e0, e1))
+                    if self.rank == 0:
+                        # ONE copy kernel straight from the receive blocks (round 3: one index_copy_ launch per rank)
+                        self._display_ext.index_copy_(0, self._dst_rows, self._recv_all.view(-1, self.r.width, 4))
+                    if timed:
+                        e2.record(self.stream)
+                        self._coll_events.append((e0, e2))
+                        self.__dict__.setdefault("_unpack_events", []).append((e1, e2))
             else:
                 self.r.sync()
                 h = self.r.height
@@ -169,6 +203,16 @@ class ShardedImage:
         ms = sum(a.elapsed_time(b) for a, b in ev)
         n = len(ev)
         self._coll_events = []
+        return ms, n
+
+    def unpack_time_ms(self):
+        """Rank 0: stream time of the unpacking copy of the timed gathers since the last call, and their count."""
+        ev = self.__dict__.get("_unpack_events", [])
+        if not ev:
+            return 0.0, 0
+        self.stream.synchronize()
+        ms, n = sum(a.elapsed_time(b) for a, b in ev), len(ev)
+        self._unpack_events = []
         return ms, n
 
     def read_image(self):
