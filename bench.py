@@ -165,17 +165,21 @@ def rehearsal(args, rank, world):
 
 
 def issue_calibration():
-    """profiles/r03_issue_peak.txt (tools/issue_peak.hip): wave-instructions per cycle per SIMD of independent VALU, SALU and
-    1 : 1 interleaved streams at W waves per SIMD."""
-    path = os.path.join(REPO, "profiles", "r03_issue_peak.txt")
+    """profiles/r04_issue_peak.txt (tools/issue_peak.hip): wave-instructions per cycle per SIMD of independent VALU, SALU and
+    interleaved streams at W waves per SIMD — the WALL-CLOCK rate of >= 10 ms launches (round 3 quoted the rate derived from
+    per-workgroup s_memtime spans of 1 ms launches, which over-states it 1.4-2.0 x: profiles/r04_issue_peak.txt has both
+    columns).  Returns {stream name: {waves: rate}}."""
+    import re
+    path = os.path.join(REPO, "profiles", "r04_issue_peak.txt")
     out = {}
     try:
         for line in open(path):
-            m = line.split()
-            if len(m) >= 4 and m[0] in ("v_add_f32", "s_add_u32"):
-                kind = "mixed" if (len(m) >= 6 and m[1] == ":") else ("valu" if m[0] == "v_add_f32" else "salu")
-                waves, rate = (int(m[3]), float(m[4])) if kind == "mixed" else (int(m[1]), float(m[2]))
-                out.setdefault(kind, {})[waves] = rate
+            f = re.split(r"\s{2,}", line.strip())
+            if len(f) >= 4 and f[1].isdigit():
+                try:
+                    out.setdefault(f[0], {})[int(f[1])] = float(f[3])      # name, waves, span-derived, WALL-CLOCK, ...
+                except ValueError:
+                    pass
     except OSError:
         return None
     return out or None
@@ -275,7 +279,7 @@ def main():
 
         def step(timed=False):
             r.resetAccumulation()
-            shard.render(frames, batch=batch)
+            shard.render(frames, batch=batch, timed=timed)
             shard.gather(present=True, timed=timed)
 
         for _ in range(warmup):
@@ -290,6 +294,16 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         coll_ms, coll_n = shard.collective_time_ms() if distributed else (0.0, 0)
+        unpack_ms, unpack_n = shard.unpack_time_ms() if distributed else (0.0, 0)
+        rend_ms, rend_n = shard.render_time_ms() if distributed else (0.0, 0)
+        render_ms = None
+        if distributed and rend_n:
+            # this rank's stream time in its own dispatches per image: min / max over the ranks = the load balance of the stripes
+            mine = torch.tensor([rend_ms / rend_n], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            render_ms = {"min": round(float(lo.item()), 4), "max": round(float(hi.item()), 4)}
         ktimes = r.kernelTimes()
         r.setKernelTiming(False)
         counts = r.getCounters()
@@ -305,6 +319,7 @@ def main():
         r.setCounting(False)
         return {"bridge": bridge, "renderer": r, "shard": shard, "elapsed": elapsed, "rays": rays_total,
                 "ktimes": ktimes, "kc": kc, "steps": steps, "collective_ms": coll_ms / coll_n if coll_n else None,
+                "unpack_ms": unpack_ms / unpack_n if unpack_n else None, "render_ms": render_ms,
                 "wire_bytes_per_rank": shard.wire_bytes_per_rank() if distributed else 0}
 
     def live_loop(scene, nframes, depth, width=WIDTH, height=HEIGHT, passes=3, lookahead=0):
@@ -334,10 +349,75 @@ def main():
         c = r.getCounters()
         r.destroy()
         rays = c["primary_rays"] + c["extension_rays"] + c["shadow_rays"]
-        return {"scene": scene, "workload": "%s %dx%d depth %d: %d x { compute(f); present() }, %s" % (
-                    scene, width, height, depth, nframes, "frames traced ahead (rt_set_lookahead %d)" % lookahead if lookahead > 1 else "one dispatch per frame"),
-                "lookahead": lookahead,
-                "ms_per_frame": round(dt / (passes * nframes) * 1e3, 4), "Mrays_s": round(rays / dt / 1e6, 1), "frames": passes * nframes}
+        e = {"scene": scene, "workload": "%s %dx%d depth %d: %d x { compute(f); present() }, %s" % (
+                 scene, width, height, depth, nframes, "frames traced ahead (rt_set_lookahead %d)" % lookahead if lookahead > 1 else "one dispatch per frame"),
+             "lookahead": lookahead, "ms_per_frame": round(dt / (passes * nframes) * 1e3, 4), "frames": passes * nframes}
+        if lookahead > 1:
+            # with lookahead the device counters count a frame when it is TRACED, the <= lookahead - 1 frames traced in vain
+            # at the end of every pass included: that is not the rate of the frames shown
+            e["Mrays_s_traced_incl_frames_traced_in_vain"] = round(rays / dt / 1e6, 1)
+        else:
+            e["Mrays_s"] = round(rays / dt / 1e6, 1)
+            e["rays_per_displayed_frame"] = rays / float(passes * nframes)
+        return e
+
+    def animated_live_loop(kind, frames=24, width=WIDTH, height=HEIGHT):
+        """renderFrame of src/main.ts:119-181 on an ANIMATED world, the world advanced before every displayed frame (so no
+        frame can be traced ahead): update(t) -> sync -> compute(1) -> present(), device-resident update (rt_world_update).
+        kind "tube": a fully skinned 262 144-triangle glTF; "hall": a skinned 9 216-triangle character inside a static
+        262 144-triangle mesh (tests/test_gltf.py builds both).  ms per displayed frame, split by phase."""
+        import test_gltf
+        if kind == "hall":
+            glb, n_static, n_skinned = test_gltf.character_in_hall_glb(pkg, (512, 256))
+            what = "%d static + %d skinned triangles" % (n_static, n_skinned)
+        else:
+            glb, n_tris = test_gltf.big_skinned_glb(pkg, 512, 256)
+            what = "%d skinned triangles" % n_tris
+        res = {"scene": "animated glTF (%s): %s, %dx%d depth %d, world advanced every displayed frame" % (kind, what, width, height, DEPTH)}
+        for mode in ("device_resident", "host_cpu_builder"):
+            r = pkg.WebGPURenderer(local_rank)
+            r.buildPipeline(DEPTH, 1)
+            b = pkg.WorldBridge(zero_copy=True)
+            if mode == "device_resident":
+                b.setDeviceUpdater(r)
+            b.loadScene("viewer", glbData=glb)
+            pkg.upload_scene(r, b, width, height)
+            n = frames if mode == "device_resident" else 2      # the reference's way costs 0.1 s per update
+            tick = 0
+            for _ in range(3 if mode == "device_resident" else 1):   # the device path learns the trees' depths on its first updates
+                tick += 1
+                b.update(tick / 60)
+                pkg.sync_world(r, b, width, height)
+                r.compute(1)
+                r.present()
+            r.sync()
+            t_upd = t_sync = t_trace = t_gpu = 0.0
+            for _ in range(n):
+                tick += 1
+                t0 = time.perf_counter()
+                b.update(tick / 60)
+                t1 = time.perf_counter()
+                if mode == "device_resident":
+                    if not b.deviceResident:
+                        raise SystemExit("bench.py: the device-resident update fell back to the host: " + b.deviceWarning)
+                    t_gpu += r.worldLastMs()
+                pkg.sync_world(r, b, width, height)
+                t2 = time.perf_counter()
+                r.compute(1)
+                r.present()
+                r.sync()
+                t3 = time.perf_counter()
+                t_upd += t1 - t0
+                t_sync += t2 - t1
+                t_trace += t3 - t2
+            e = {"update_ms": round(t_upd / n * 1e3, 3), "upload_ms": round(t_sync / n * 1e3, 3),
+                 "trace_present_ms": round(t_trace / n * 1e3, 3), "frames_per_s": round(n / (t_upd + t_sync + t_trace), 1), "frames": n}
+            if mode == "device_resident":
+                e["update_gpu_stream_ms"] = round(t_gpu / n, 3)
+            res[mode] = e
+            b.close()
+            r.destroy()
+        return res
 
     def world_update_block(scene="sponza_like", width=WIDTH, height=HEIGHT):
         """World::update(t) + the scene sync of the live loop (src/main.ts:133-163) on config 4's scene, three ways: the
@@ -347,7 +427,9 @@ def main():
         r = pkg.WebGPURenderer(local_rank)
         r.buildPipeline(DEPTH, 1)
         res = {"scene": scene}
-        for mode, reps in (("host_cpu_builder", 2), ("host_gpu_blas_hook", 5), ("device_resident", 20), ("device_resident_static_cached", 20)):
+        # (an all-static world with the static-geometry cache on is left untouched by an update: nothing to time.  The case
+        # the cache is for - a skinned character inside a large static mesh - is timed by animated_live_loop("hall").)
+        for mode, reps in (("host_cpu_builder", 2), ("host_gpu_blas_hook", 5), ("device_resident", 20)):
             b = pkg.WorldBridge(zero_copy=True)
             if mode == "host_gpu_blas_hook":
                 b.setBlasBuilder(r)
@@ -355,7 +437,7 @@ def main():
                 b.setDeviceUpdater(r)
                 # the scene is static: with the cache (the default) only TLAS, instances and lights are redone per frame;
                 # without it every frame skins, builds and packs everything - the cost of a fully animated world
-                r.setWorldStaticCache(mode.endswith("cached"))
+                r.setWorldStaticCache(False)
             b.loadScene(scene)
             pkg.upload_scene(r, b, width, height)
             res["triangles"] = len(b.mesh_topology) // 20
@@ -385,6 +467,40 @@ def main():
         r.destroy()
         res["device_over_host"] = round((res["host_cpu_builder"]["update_ms"] + res["host_cpu_builder"]["upload_ms"]) /
                                         (res["device_resident"]["update_ms"] + res["device_resident"]["upload_ms"]), 1)
+        # the TLAS of World::update (bvh/tlas.rs:58-111) where it matters: config 3's 1 001 instances and the 16 384 the device
+        # path takes (k_tlas: LDS bitonic sort per depth); stream time of the kernel alone beside the whole device update and
+        # the host's TLAS builder on the same instances
+        tl = []
+        for sc in ("instanced1000", "instanced16384"):
+            r = pkg.WebGPURenderer(local_rank)
+            r.buildPipeline(DEPTH, 1)
+            r.setWorldStaticCache(False)
+            b = pkg.WorldBridge(zero_copy=True)
+            b.setDeviceUpdater(r)
+            b.loadScene(sc)
+            pkg.upload_scene(r, b, width, height)
+            for _ in range(3):
+                b.update(0.0)
+            r.sync()
+            t_all = t_tlas = 0.0
+            reps = 10
+            for _ in range(reps):
+                b.update(0.0)
+                if not b.deviceResident:
+                    raise SystemExit("bench.py: the device-resident update fell back to the host: " + b.deviceWarning)
+                t_all += r.worldLastMs()
+                t_tlas += r.worldLastTlasMs()
+            hb = pkg.WorldBridge(zero_copy=True)
+            hb.loadScene(sc)
+            t0 = time.perf_counter()
+            hb.update(0.0)
+            t_host = time.perf_counter() - t0
+            tl.append({"scene": sc, "instances": len(b.instances) // 36, "k_tlas_ms": round(t_tlas / reps, 4),
+                       "device_update_gpu_stream_ms": round(t_all / reps, 4), "host_update_ms": round(t_host * 1e3, 3)})
+            hb.close()
+            b.close()
+            r.destroy()
+        res["tlas"] = tl
         return res
 
     frames = list(range(1, SPP_TOTAL + 1))
@@ -440,16 +556,26 @@ def main():
                 roof["frac_of_measured_issue_peak"] = round(roof["achieved"] / pt["measured_issue_peak_Tlane"], 4)
             ic = issue_calibration()
             if ic and pt.get("insts_valu_per_launch") and pt.get("insts_salu_per_launch") and pt.get("effective_clock_GHz"):
-                # the kernel's whole instruction stream (vector + scalar + LDS) against what a SIMD issues of a 1 : 1 vector /
-                # scalar stream at this kernel's 4 waves per SIMD: the bound the walks actually run into
-                insts = (pt["insts_valu_per_launch"] + pt["insts_salu_per_launch"] + pt.get("insts_lds_per_launch", 0.0)) * scale
+                # Round 3 called the kernel "issue-bound at 0.79" against span-derived rates that wall clock does not confirm.
+                # By wall clock (tools/issue_peak.hip, >= 10 ms launches) a SIMD with 4 resident waves issues 0.40 independent
+                # v_add_f32 per cycle, 0.23 s_add_u32 (the scalar unit is shared by the CU's four SIMDs: 0.25), and of a
+                # 3 : 1 vector : scalar stream - this kernel's mix - what the "3 v_add : 1 s_add" rows say.
+                scale_i = scale
+                valu = pt["insts_valu_per_launch"] * scale_i
+                salu = pt["insts_salu_per_launch"] * scale_i
+                lds = pt.get("insts_lds_per_launch", 0.0) * scale_i
                 simd_cycles = launch_ms * 1e-3 * pt["effective_clock_GHz"] * 1e9 * 256 * 4
-                rate = insts / simd_cycles
-                roof["issue"] = {"wave_instr_per_cycle_per_simd": round(rate, 4), "waves_per_simd": 4,
-                                 "measured_mixed_issue_rate": ic.get("mixed", {}).get(4), "measured_valu_only": ic.get("valu", {}).get(4),
-                                 "measured_salu_only": ic.get("salu", {}).get(4),
-                                 "frac_of_measured_mixed_issue_rate": round(rate / ic["mixed"][4], 4) if ic.get("mixed", {}).get(4) else None,
-                                 "source": "instruction counts: " + str(src) + "; issue rates: profiles/r03_issue_peak.txt (tools/issue_peak.hip)"}
+                mix = ic.get("3 v_add : 1 s_add (mixed)", {}).get(4)
+                roof["issue"] = {"waves_per_simd": 4,
+                                 "valu_instr_per_cycle_per_simd": round(valu / simd_cycles, 4),
+                                 "salu_instr_per_cycle_per_simd": round(salu / simd_cycles, 4),
+                                 "all_instr_per_cycle_per_simd": round((valu + salu + lds) / simd_cycles, 4),
+                                 "wall_clock_peak_valu_only": ic.get("v_add_f32", {}).get(4),
+                                 "wall_clock_peak_salu_only": ic.get("s_add_u32", {}).get(4),
+                                 "wall_clock_peak_3to1_mix": mix,
+                                 "valu_frac_of_wall_clock_valu_peak": round(valu / simd_cycles / ic["v_add_f32"][4], 4) if ic.get("v_add_f32", {}).get(4) else None,
+                                 "all_frac_of_wall_clock_3to1_peak": round((valu + salu + lds) / simd_cycles / mix, 4) if mix else None,
+                                 "source": "instruction counts: " + str(src) + "; issue rates: profiles/r04_issue_peak.txt (tools/issue_peak.hip, wall-clock column)"}
             if pt.get("hbm_bytes_per_launch"):
                 tb = pt["hbm_bytes_per_launch"] * scale
                 roof["traffic"] = tb
@@ -480,6 +606,10 @@ def main():
             # pack + gather + unpack on rank 0's stream, per image (events around the collective section)
             out["collective_ms"] = round(head["collective_ms"], 4) if head["collective_ms"] is not None else None
             out["collective_bytes_per_rank"] = head["wire_bytes_per_rank"]
+            # of it: rank 0's unpacking copy (one kernel from the receive blocks into the display buffer); and what each rank
+            # spends in its own dispatches per image (stream time, min / max over the ranks): the balance of the stripes
+            out["unpack_ms"] = round(head["unpack_ms"], 4) if head["unpack_ms"] is not None else None
+            out["rank_render_ms_per_image"] = head["render_ms"]
         cfgs = []
         for name, scene, nframes, depth, m, cw, ch in extra:
             kt, kc = m["ktimes"], m["kc"]
@@ -498,6 +628,8 @@ def main():
             if distributed:
                 entry["collective_ms"] = round(m["collective_ms"], 4) if m["collective_ms"] is not None else None
                 entry["collective_bytes_per_rank"] = m["wire_bytes_per_rank"]
+                entry["unpack_ms"] = round(m["unpack_ms"], 4) if m["unpack_ms"] is not None else None
+                entry["rank_render_ms_per_image"] = m["render_ms"]
             if per_image_trace_ms > 0:
                 gbps = trace_bytes / (per_image_trace_ms * 1e-3) / 1e9
                 rk = ref.get("k_wf_trace", {}).get(scene, {}) if (world == 1 and not ref.get("_stale")) else {}
@@ -542,10 +674,17 @@ def main():
             for scene, depth in ((SCENE, DEPTH), ("sponza_like", 8)):
                 if scene != SCENE and args.no_extra_configs:
                     continue
+                rays_per_frame = None
                 for look in (0, 32):
                     # 256 frames per pass: a live view accumulates until the camera moves; the run must be long against the
                     # lookahead's ramp (1, 2, 4, ... frames) and against what is traced ahead in vain when it ends
                     e = live_loop(scene, 256, depth, lookahead=look, passes=2)
+                    if look == 0:
+                        rays_per_frame = e.pop("rays_per_displayed_frame")
+                    elif rays_per_frame:
+                        # rays of the frames DISPLAYED (frames x the per-frame count of the one-dispatch-per-frame run of the
+                        # same 256 frames: the counts are deterministic) over the same wall time
+                        e["Mrays_s"] = round(rays_per_frame / (e["ms_per_frame"] * 1e-3) / 1e6, 1)
                     if scene in batched:
                         e["batched_ms_per_frame"] = round(batched[scene], 4)
                         e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
@@ -553,11 +692,15 @@ def main():
                 # the same with a still view four times as long: the ramp and the (at most 31) frames traced in vain when the
                 # run ends are a fixed cost per run, so the ratio depends on how long the camera rests
                 e = live_loop(scene, 1024, depth, lookahead=32, passes=1)
+                if rays_per_frame:   # frames 257..1024 count within a fraction of a percent of the first 256: an estimate, said so
+                    e["Mrays_s_displayed_est"] = round(rays_per_frame / (e["ms_per_frame"] * 1e-3) / 1e6, 1)
                 if scene in batched:
                     e["batched_ms_per_frame"] = round(batched[scene], 4)
                     e["live_over_batched"] = round(e["ms_per_frame"] / batched[scene], 3)
                 ll.append(e)
             out["live_loop"] = ll
+            if not args.no_world_update:
+                out["live_loop_animated"] = [animated_live_loop("tube"), animated_live_loop("hall")]
         if world == 1 and not args.no_world_update:
             out["world_update"] = world_update_block()
         if world == 1 and not args.no_cpu_baseline:

@@ -229,7 +229,11 @@ int rt_build_blas_levels(const rt_ctx* ctx);
  * to the device when frame->static_epoch differs from the last call's; the pointers need only live during the call.
  * One stream synchronisation at the end (node counts, the TLAS root).  Returns RT_OK / RT_REALLOCATED, or < 0: a
  * description this path does not take (an instance of an empty geometry, a NaN instance box; the caller then runs the
- * host update and uploads as before) or an error. */
+ * host update and uploads as before) or an error.  The update writes into the live scene buffers: after a failure that
+ * came when its kernels had started (a NaN instance box, a tree that did not settle) those hold a mix of two scenes and
+ * rt_compute refuses with RT_ERR_INVALID until the scene has been uploaded again (rt_upload* / rt_upload_geometry /
+ * rt_upload_bvh); a refusal of the arguments (null arrays, a skin table that does not match the static description) is made
+ * before anything is written and leaves the previous scene renderable. */
 int rt_world_update(rt_ctx* ctx, const rt_world_frame* frame);
 /* A geometry without a skin has the same vertices in every frame of a static description, hence the same BLAS, topology
  * rows and emissive list: after the first update rt_world_update leaves its rows in place and copies its node block from a
@@ -238,6 +242,8 @@ int rt_world_update(rt_ctx* ctx, const rt_world_frame* frame);
 int rt_world_set_static_cache(rt_ctx* ctx, int enabled);
 /* Stream time (ms, HIP events) of the last rt_world_update: kernels and the small copies, without host work. */
 double rt_world_last_ms(const rt_ctx* ctx);
+/* ... and of its TLAS kernel alone (k_tlas: instance boxes, median-split tree, packed instances). */
+double rt_world_last_tlas_ms(const rt_ctx* ctx);
 /* Read a bridge array back from the device-resident world (tests; a host that wants the arrays after all).  out == NULL:
  * only *bytes_out is set. */
 typedef enum rt_world_array {

@@ -22,11 +22,11 @@ def _same(r, cpu_b, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene", ["cornell", "mixed", "special", "instanced1000", "sponza_like", "glass_blob", "skinned_tube",
-                                   "skinned_small", "character_in_hall"])
+@pytest.mark.parametrize("scene", ["cornell", "mixed", "special", "instanced1000", "instanced16384", "sponza_like", "glass_blob",
+                                   "skinned_tube", "skinned_small", "character_in_hall"])
 def test_device_update_equals_the_host_update(W, scene):
-    """Every bridge array, byte for byte: the static scenes (1 to 1 001 instances: the TLAS sort, rotation and light
-    lists), the two 200 k+ triangle meshes (large-node levels of the builder) and skinned, animated glTFs at three times."""
+    """Every bridge array, byte for byte: the static scenes (1 to 16 384 instances - the most the device TLAS takes, a lattice
+    full of equal centres: the stable sort, rotation and light lists), the two 200 k+ triangle meshes (large-node levels of the builder) and skinned, animated glTFs at three times."""
     r = W.WebGPURenderer(0)
     glb, name, times = None, scene, (0.0,)
     if scene == "skinned_tube":
@@ -342,4 +342,66 @@ def test_device_tlas_equals_the_hand_derived_arrays(W, case):
     assert got == kat["nodes"]
     out_inst = r.worldRead("instances").reshape(-1, 36)
     assert [int(v) for v in out_inst[:, 34].view(np.uint32)] == kat["order"]      # instance_id = the geometry = the input index
+    r.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("n,seed", [(2, 1), (3, 2), (63, 3), (64, 4), (65, 5), (129, 10), (1000, 6), (1024, 7), (1025, 8), (4097, 9)])
+def test_device_tlas_on_random_and_tied_instance_sets(W, monkeypatch, n, seed, generic):
+    """k_tlas / k_tlas_small against the CPU builder (ms_build_tlas) on instance sets built to be awkward for the sort: random boxes, many
+    exactly equal centres (ties decided by the current order, depth after depth), centres at -0 / +0, counts around the
+    wave, workgroup and power-of-two sizes of the bitonic network.  One single-triangle geometry per instance, translated."""
+    import ctypes
+    from test_world_device_hook import Frame, Geometry
+    from test_bvh_independent import cpu_build_tlas
+    if generic:                 # up to 1 024 instances take k_tlas_small (one position per lane); this forces k_tlas for them too
+        if n > 1024:
+            pytest.skip("k_tlas is what runs above 1 024 instances anyway")
+        monkeypatch.setenv("MI355RT_TLAS_GENERIC", "1")
+    f32 = np.float32
+    rng = np.random.default_rng(seed)
+    lo = rng.integers(-8, 8, (n, 3)).astype(f32) * f32(0.25)
+    if seed % 2 == 0:
+        lo[:, rng.integers(0, 3)] = 0                  # every centre equal on one axis
+    lo[rng.random(n) < 0.3] = lo[0]                     # 30 % of the instances share one box
+    ext = rng.integers(1, 4, (n, 3)).astype(f32) * f32(0.5)
+    if n >= 3:
+        lo[1], ext[1] = (-0.5, 0.25, 0.0), (1.0, 0.5, 1.0)      # centre x = +0
+        lo[2], ext[2] = (0.5, 0.25, 0.0), (-1.0, 0.5, 1.0)      # box given max-first: min/max swap, centre x = (0.5 + -0.5) / 2 = 0
+    boxes = np.concatenate([np.minimum(lo, lo + ext), np.maximum(lo, lo + ext)], axis=1)
+    want_nodes, want_order = cpu_build_tlas(W, boxes.tolist())
+    fp, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)
+    keep, geos, rows = [], [], []
+    nrm = np.tile(np.array([0, 0, 1], f32), (3, 1))
+    joints, weights = np.zeros((3, 4), np.uint32), np.zeros((3, 4), f32)
+    idx, attr = np.array([0, 1, 2], np.uint32), np.full((1, 16), 0.5, f32)
+    for gi in range(n):
+        x0, y0, z0, x1, y1, z1 = boxes[gi]
+        pos = np.array([[x0, y0, z0], [x1, y1, z0], [x0, y0, z1]], f32)
+        keep.append(pos)
+        g = Geometry()
+        g.positions, g.normals, g.uvs = pos.ctypes.data_as(fp), nrm.ctypes.data_as(fp), None
+        g.joints, g.weights = joints.ctypes.data_as(up), weights.ctypes.data_as(fp)
+        g.indices, g.attributes = idx.ctypes.data_as(up), attr.ctypes.data_as(fp)
+        g.n_verts, g.n_uvs, g.n_tris, g.skin = 3, 0, 1, -1
+        geos.append(g)
+        row = np.zeros(36, f32)
+        row[:16] = np.eye(4, dtype=f32).reshape(-1)
+        row[16:32] = np.eye(4, dtype=f32).reshape(-1)
+        row[32:].view(np.uint32)[:] = (0, 0, gi, 0)
+        rows.append(row)
+    inst = np.stack(rows)
+    arr = (Geometry * n)(*geos)
+    fr = Frame()
+    fr.static_epoch, fr.n_geometries, fr.n_instances, fr.n_skins = 8000 + seed, n, n, 0
+    fr.geometries, fr.instances = arr, inst.ctypes.data_as(fp)
+    r = W.WebGPURenderer(0)
+    rc = r.L.rt_world_update(r.ctx, ctypes.byref(fr))
+    assert rc >= 0, r.L.rt_last_error(r.ctx).decode()
+    tlas = r.worldRead("tlas").reshape(-1, 8)
+    u = tlas.view(np.uint32)
+    got = [{"min": tlas[i, 0:3].tolist(), "skip": int(u[i, 3]), "max": tlas[i, 4:7].tolist(), "data": int(u[i, 7])} for i in range(len(tlas))]
+    assert [int(v) for v in r.worldRead("instances").reshape(-1, 36)[:, 34].view(np.uint32)] == want_order
+    assert got == want_nodes
     r.destroy()

@@ -1,5 +1,5 @@
 // issue_peak.hip — how many instructions per cycle one SIMD of an MI355X issues from W resident waves, by instruction kind:
-// independent v_add_f32 (VALU), independent s_add_u32 (SALU), and the two interleaved 1 : 1 — the mix the traversal kernels
+// independent v_add_f32 (VALU), independent s_add_u32 (SALU), the two interleaved 1 : 1 and 3 : 1 — the mixes the traversal kernels
 // run (PMC: 0.4-0.8 scalar instructions per vector instruction; lane masks, ballots, branches).  The walks of this renderer
 // are neither bandwidth- nor FLOP-bound: they are bound by how fast a SIMD ISSUES their serial, mask-heavy instruction streams
 // (DESIGN.md 4.1c); this tool gives that bound a measured denominator.
@@ -32,6 +32,8 @@
 #define VS8 "v_add_f32 %0, %0, %16\n s_add_u32 %8, %8, 1\n v_add_f32 %1, %1, %16\n s_add_u32 %9, %9, 1\n v_add_f32 %2, %2, %16\n s_add_u32 %10, %10, 1\n v_add_f32 %3, %3, %16\n s_add_u32 %11, %11, 1\n" \
             "v_add_f32 %4, %4, %16\n s_add_u32 %12, %12, 1\n v_add_f32 %5, %5, %16\n s_add_u32 %13, %13, 1\n v_add_f32 %6, %6, %16\n s_add_u32 %14, %14, 1\n v_add_f32 %7, %7, %16\n s_add_u32 %15, %15, 1\n"
 
+#define VVVS8 "v_add_f32 %0, %0, %16\n v_add_f32 %1, %1, %16\n v_add_f32 %2, %2, %16\n s_add_u32 %8, %8, 1\n v_add_f32 %3, %3, %16\n v_add_f32 %4, %4, %16\n v_add_f32 %5, %5, %16\n s_add_u32 %9, %9, 1\n"
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_issue(int iters, float* out, unsigned long long* stamps) {
   float a[8];
@@ -51,6 +53,8 @@ __global__ __launch_bounds__(256) void k_issue(int iters, float* out, unsigned l
     if (KIND == 0) asm volatile(V8 V8 V8 V8 OPERANDS);                       // 32 VALU
     if (KIND == 1) asm volatile(S8 S8 S8 S8 OPERANDS);                       // 32 SALU
     if (KIND == 2) asm volatile(VS8 VS8 OPERANDS);                           // 16 VALU + 16 SALU, alternating
+    if (KIND == 3) asm volatile(V8 S8 V8 V8 OPERANDS);                       // 24 VALU + 8 SALU (3 : 1, the path-trace kernel's mix), in runs of 8
+    if (KIND == 4) asm volatile(VVVS8 VVVS8 VVVS8 VVVS8 OPERANDS);           // 24 VALU + 8 SALU, a scalar instruction after every third vector one
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float acc = 0.0f;
@@ -76,9 +80,9 @@ int main() {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  printf("%-22s %-10s %20s %20s %12s %10s %16s\n", "stream", "waves/SIMD", "instr/cyc/SIMD (span)", "instr/cyc/SIMD (wall)", "clock GHz", "ms", "T lane-instr/s");
-  const char* names[3] = {"v_add_f32", "s_add_u32", "v_add_f32 : s_add_u32"};
-  for (int kind = 0; kind < 3; kind++) {
+  printf("%-28s %-10s %20s %20s %12s %10s %16s\n", "stream", "waves/SIMD", "instr/cyc/SIMD (span)", "instr/cyc/SIMD (wall)", "clock GHz", "ms", "T lane-instr/s");
+  const char* names[5] = {"v_add_f32", "s_add_u32", "v_add_f32 : s_add_u32", "3 v_add : 1 s_add (runs)", "3 v_add : 1 s_add (mixed)"};
+  for (int kind = 0; kind < 5; kind++) {
     for (int waves : {1, 2, 4, 5, 6, 8}) {
       const int iters = 400000, grid = cus * waves;   // 12.8 M instructions per wave: >= 10 ms per launch
       float ms = 0.f;
@@ -87,6 +91,8 @@ int main() {
         if (kind == 0) hipLaunchKernelGGL(k_issue<0>, dim3(grid), dim3(256), 0, 0, iters, out, stamps);
         if (kind == 1) hipLaunchKernelGGL(k_issue<1>, dim3(grid), dim3(256), 0, 0, iters, out, stamps);
         if (kind == 2) hipLaunchKernelGGL(k_issue<2>, dim3(grid), dim3(256), 0, 0, iters, out, stamps);
+        if (kind == 3) hipLaunchKernelGGL(k_issue<3>, dim3(grid), dim3(256), 0, 0, iters, out, stamps);
+        if (kind == 4) hipLaunchKernelGGL(k_issue<4>, dim3(grid), dim3(256), 0, 0, iters, out, stamps);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -102,9 +108,9 @@ int main() {
       // wall clock: every SIMD of the chip holds `waves` waves, each issuing iters x 32 instructions, in `ms` at `clk` GHz
       const double wall_cycles = (double)ms * 1e-3 * clk * 1e9;
       const double wall_rate = (double)waves * iters * 32.0 / wall_cycles;
-      const double vec_share = kind == 0 ? 1.0 : (kind == 1 ? 0.0 : 0.5);
+      const double vec_share = kind == 0 ? 1.0 : (kind == 1 ? 0.0 : (kind == 2 ? 0.5 : 0.75));
       const double lane_rate = (double)grid * 256.0 * iters * 32.0 * vec_share / ((double)ms * 1e-3) / 1e12;
-      printf("%-22s %-10d %20.3f %20.3f %12.2f %10.2f %16.2f\n", names[kind], waves, (double)waves * iters * 32.0 / cyc, wall_rate, clk, ms,
+      printf("%-28s %-10d %20.3f %20.3f %12.2f %10.2f %16.2f\n", names[kind], waves, (double)waves * iters * 32.0 / cyc, wall_rate, clk, ms,
              lane_rate);
       fflush(stdout);
     }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Lane utilisation of k_pathtrace_persistent by part of a trip, beside the share of the wave's cycles each section takes
-(Cornell, one 32-frame batch of the bench workload).  Two DIAGNOSTIC builds: -DRT_LANE_STATS (a ballot + two atomics where a
-wave enters a part: counts, no timing) and -DRT_PT_STAMPS (s_memtime around the five sections: timing).  Rebuilds the product
-library at the end.  usage: lane_stats.py [scene]"""
+"""Lane utilisation of k_pathtrace_persistent by part of a trip (Cornell, one 32-frame batch of the bench workload).
+DIAGNOSTIC build -DRT_LANE_STATS: a ballot + two atomics where a wave enters a part (counts, no timing; the share of a wave's
+cycles each section takes comes from tools/pt_sections.py, its own process and build).  Rebuilds the product library at the end.
+usage: lane_stats.py [scene]"""
 import ctypes
 import os
 import sys
@@ -45,17 +45,6 @@ try:
     for k, name in enumerate(PARTS):
         if n[k]:
             print("   %-34s %14.2f %12.1f %12.3f" % (name, n[k] / trips, lanes[k] / n[k], lanes[k] / n[k] / 64.0))
-    r.destroy()
-    r, fl = render(["-DRT_PT_STAMPS"])
-    sec = np.zeros(8, dtype=np.uint64)
-    r.L.rt_debug_pt_sections(r.ctx, sec.ctypes.data_as(ctypes.c_void_p), 1)
-    r.computeBatch(fl)
-    r.sync()
-    r.L.rt_debug_pt_sections(r.ctx, sec.ctypes.data_as(ctypes.c_void_p), 1)
-    cyc, t2 = sec[:5].astype(float), float(sec[5])
-    print("   cycles per trip by section (s_memtime): " + ", ".join(
-        "%s %.0f (%.1f %%)" % (nm, c / t2, 100 * c / cyc.sum())
-        for nm, c in zip(("regenerate + start", "shade", "shadow walk", "extension walk + surface", "finish"), cyc)))
     r.destroy()
 finally:
     W._build.build_rt(force=True)

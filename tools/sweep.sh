@@ -10,6 +10,8 @@
 RUNS=${RUNS:-"sponza_like 1920 1080 8;instanced1000 1920 1080 8;glass_blob 3840 2160 16"}
 FRAMES=${FRAMES:-32}; BATCH=${BATCH:-32}; KVARIANT=${KVARIANT:-3}
 run() { echo "$RUNS" | tr ';' '\n' | while read s w h d; do env $ENVS timeout -k 10 200 python tools/prof_frames.py $s $w $h $FRAMES $d $KVARIANT 0 1 $BATCH 2>&1 | grep "kernel ms" | sed "s/.*kernel ms (sum over the run): /$s /" | tr '\n' ' '; done; echo; }
+# the product build is restored on ANY exit (a variant library left behind would be taken for the product one)
+trap 'python -c "import webgpu_raytracer_amd._build as b; b.build_rt(force=True)" > /dev/null 2>&1' EXIT
 build() { python - <<PY
 import webgpu_raytracer_amd as W
 W._build.build_rt(force=True, extra_flags="$1".split())

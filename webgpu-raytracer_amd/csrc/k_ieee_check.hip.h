@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_ieee_check(unsigned long long first, un
     const unsigned long long k = t * stride + (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
     const bool live = k < count;
     const unsigned long long i = first + (live ? k : 0ull);
+    (void)i;
     if (!live) continue;
 #if defined(MI355RT_DEVICE_IEEE)
     if (OP == RT_IEEE_OP_RCP || OP == RT_IEEE_OP_SQRT || OP == RT_IEEE_OP_RSQRT || OP == RT_IEEE_OP_DIV_PI) {

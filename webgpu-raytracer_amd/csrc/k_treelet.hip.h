@@ -201,6 +201,14 @@ __global__ __launch_bounds__(1024) void k_treelet_number(TreeletArgs A, const ui
   A.new_index[i] = sel ? sel_before : total_sel + (i - sel_before);
 }
 
+// identity numbering (tnodes in the bridge's depth-first order): what a device-resident update(t) uses — the numbering
+// passes above are 7 of the 10 launches of this re-layout, and their order only pays when a PREFIX of tnodes is staged in
+// LDS (MI355RT_TREELET_MAX), which the default plan never does (rt_api.hip plan_lds)
+__global__ __launch_bounds__(256) void k_treelet_iota(uint32_t* __restrict__ new_index, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) new_index[i] = i;
+}
+
 __global__ __launch_bounds__(256) void k_treelet_remap(TreeletArgs A) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= A.n_nodes) return;

@@ -72,7 +72,7 @@ struct rt_ctx {
     std::vector<uint32_t> levels, big_levels;   // per geometry: tree levels / large-node levels the next build launches
     std::vector<float> inst_scale2;       // per instance (declaration order): squared linear scale (treelet weights)
     std::vector<uint32_t> inst_geom;
-    uint32_t n_joints = 0, n_verts = 0, n_tris = 0, n_lights = 0, n_tlas = 0, n_inst = 0;
+    uint32_t n_joints = 0, n_verts = 0, n_tris = 0, n_lights = 0, n_tlas = 0, n_inst = 0, n_skins = 0;
     DeviceBuffer stat, joints, raw_inst, geom_rows, node_base, em_flag, em_list, em_blk, tlas_scratch, stats;
     void* pinned = nullptr;               // joint-matrix staging and the end-of-update read-back
     size_t pinned_bytes = 0;
@@ -82,7 +82,9 @@ struct rt_ctx {
     DeviceBuffer static_nodes;
     std::vector<uint32_t> static_count, static_off;   // per geometry: cached node count, first node in static_nodes
     double last_ms = 0;                   // stream time of the last update (rt_world_last_ms)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_tlas_ms = 0;              // ... of its k_tlas launch alone (rt_world_last_tlas_ms)
+    bool tlas_lds_set = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   } world;
   // derived buffers (device_scene.h)
   DeviceBuffer tri_geom, tri_shade, inst_trav, light_rec;
@@ -135,6 +137,8 @@ struct rt_ctx {
                                  // batch; glass blob, 2 instances and short walks: +7 %; 1 001 instances of 8 triangles: +20 %)
   int wf_blocks_per_cu = 0;      // 0 = default for the block size (MI355RT_WF_BLOCKS_PER_CU)
   long treelet_cap = -1;
+  int treelet_order = 2;          // order of tnodes: 0 = by visit probability, 1 = the bridge's depth-first order, 2 = auto (MI355RT_TREELET_ORDER)
+  bool nodes_from_device = false; // the node array was made by rt_world_update (an animated world), not uploaded
   size_t occ_dyn[4] = {0, 0, 0, 0};
   DeviceBuffer ticket;    // tile ticket counter of the persistent kernel
   DeviceBuffer slots;     // DevFrameSlot table of the current (batched) dispatch
@@ -376,14 +380,22 @@ int prepare_scene(rt_ctx* c) {
     uint32_t* work = (uint32_t*)c->treelet_work.ptr;
     HIP_TRY(c, hipMemsetAsync(work, 0, (size_t)RT_TREELET_WORK_HEAD * 4, c->stream));
     const dim3 hgrid(std::min<uint32_t>((c->n_nodes + 255) / 256, 256u));
-    hipLaunchKernelGGL(rtk::k_treelet_weight, grid, dim3(256), 0, c->stream, T);
-    hipLaunchKernelGGL(rtk::k_treelet_hist<0>, hgrid, dim3(256), 0, c->stream, T, work);
-    hipLaunchKernelGGL(rtk::k_treelet_pick<0>, dim3(1), dim3(256), 0, c->stream, T, work);
-    hipLaunchKernelGGL(rtk::k_treelet_hist<1>, hgrid, dim3(256), 0, c->stream, T, work);
-    hipLaunchKernelGGL(rtk::k_treelet_pick<1>, dim3(1), dim3(256), 0, c->stream, T, work);
-    hipLaunchKernelGGL(rtk::k_treelet_count, dim3(n_blocks), dim3(1024), 0, c->stream, T, work);
-    hipLaunchKernelGGL(rtk::k_treelet_blockscan, dim3(1), dim3(1024), 0, c->stream, work, n_blocks);
-    hipLaunchKernelGGL(rtk::k_treelet_number, dim3(n_blocks), dim3(1024), 0, c->stream, T, (const uint32_t*)work);
+    // A device-resident update(t) (rt_world_update) re-lays the nodes out on every displayed frame: unless a partial
+    // treelet is asked for (MI355RT_TREELET_MAX) the visit-probability order buys nothing there, so it keeps the bridge's
+    // depth-first order: 3 launches instead of 10 (MI355RT_TREELET_ORDER=weight / identity forces either, for measurements)
+    const bool identity = c->treelet_order == 1 || (c->treelet_order == 2 && c->nodes_from_device && c->treelet_cap < 0);
+    if (identity) {
+      hipLaunchKernelGGL(rtk::k_treelet_iota, grid, dim3(256), 0, c->stream, T.new_index, c->n_nodes);
+    } else {
+      hipLaunchKernelGGL(rtk::k_treelet_weight, grid, dim3(256), 0, c->stream, T);
+      hipLaunchKernelGGL(rtk::k_treelet_hist<0>, hgrid, dim3(256), 0, c->stream, T, work);
+      hipLaunchKernelGGL(rtk::k_treelet_pick<0>, dim3(1), dim3(256), 0, c->stream, T, work);
+      hipLaunchKernelGGL(rtk::k_treelet_hist<1>, hgrid, dim3(256), 0, c->stream, T, work);
+      hipLaunchKernelGGL(rtk::k_treelet_pick<1>, dim3(1), dim3(256), 0, c->stream, T, work);
+      hipLaunchKernelGGL(rtk::k_treelet_count, dim3(n_blocks), dim3(1024), 0, c->stream, T, work);
+      hipLaunchKernelGGL(rtk::k_treelet_blockscan, dim3(1), dim3(1024), 0, c->stream, work, n_blocks);
+      hipLaunchKernelGGL(rtk::k_treelet_number, dim3(n_blocks), dim3(1024), 0, c->stream, T, (const uint32_t*)work);
+    }
     hipLaunchKernelGGL(rtk::k_treelet_remap, grid, dim3(256), 0, c->stream, T);
     hipLaunchKernelGGL(rtk::k_treelet_inst_roots, dim3((c->n_instances + 255) / 256), dim3(256), 0, c->stream,
                        (const float4*)c->instances.ptr, (const uint32_t*)c->node_newidx.ptr, (uint32_t*)c->inst_root.ptr,
@@ -546,6 +558,7 @@ rt_ctx* rt_create(int device_ordinal) {
     if (b == 256 || b == 512 || b == 1024) c->wf_block = b;
   }
   if (const char* e = getenv("MI355RT_TREELET_MAX")) c->treelet_cap = atol(e);
+  if (const char* e = getenv("MI355RT_TREELET_ORDER")) c->treelet_order = e[0] == 'w' ? 0 : (e[0] == 'i' ? 1 : 2);
   if (const char* e = getenv("MI355RT_WALK")) c->walk = (e[0] == 'n' || e[0] == '0') ? 0 : ((e[0] == 'a' || e[0] == '2') ? 2 : 1);   // node / pairs / auto
   if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
     const int b = atoi(e);
@@ -593,6 +606,8 @@ void rt_destroy(rt_ctx* c) {
   if (c->world.pinned) (void)hipHostFree(c->world.pinned);
   if (c->world.ev0) (void)hipEventDestroy(c->world.ev0);
   if (c->world.ev1) (void)hipEventDestroy(c->world.ev1);
+  if (c->world.ev_t0) (void)hipEventDestroy(c->world.ev_t0);
+  if (c->world.ev_t1) (void)hipEventDestroy(c->world.ev_t1);
   for (EventPair& p : c->ev_pool) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -904,7 +919,7 @@ static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
   if (!f->n_instances || !f->instances || (f->n_geometries && !f->geometries))
     return fail(c, RT_ERR_INVALID, "rt_world_update: empty scene description");
   const uint32_t G = f->n_geometries, N = f->n_instances;
-  if (N > 16384u)   // k_tlas sorts by rank counting, N^2 / 1024 comparisons per lane: fine for thousands, not for more
+  if (N > RT_TLAS_MAX_INSTANCES)   // k_tlas sorts the ranges of a depth in LDS: 16 384 64-bit keys are 128 KB of the CU's 160
     return fail(c, RT_ERR_INVALID, "rt_world_update: more than 16 384 instances are not taken by the device path");
   // layout of the static buffer (256-byte aligned arrays) and the world's totals
   size_t bytes = 0;
@@ -1028,6 +1043,8 @@ static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
   if ((r = ensure_buffer(c, c->draw_commands, (size_t)N * 16, false)) < 0) return r;
   if (!W.ev0) HIP_TRY(c, hipEventCreate(&W.ev0));
   if (!W.ev1) HIP_TRY(c, hipEventCreate(&W.ev1));
+  if (!W.ev_t0) HIP_TRY(c, hipEventCreate(&W.ev_t0));
+  if (!W.ev_t1) HIP_TRY(c, hipEventCreate(&W.ev_t1));
   W.levels.assign(G, 0u);
   W.big_levels.assign(G, 0u);
   for (uint32_t g = 0; g < G; g++) {
@@ -1060,12 +1077,13 @@ static int world_make_static(rt_ctx* c, const rt_world_frame* f) {
   A.n_lights = (uint32_t)lights;
   A.pad = 0;
   W.epoch = f->static_epoch;
+  W.n_skins = f->n_skins;
   W.valid = true;
   return grew ? RT_REALLOCATED : RT_OK;
 }
 
-int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
-  if (!c || !f) return RT_ERR_INVALID;
+// *touched is set before the first kernel that writes into the live scene buffers is enqueued
+static int world_update_body(rt_ctx* c, const rt_world_frame* f, bool* touched) {
   auto& W = c->world;
   c->epoch++;   // drops frames traced ahead (rt_set_lookahead)
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1082,7 +1100,13 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     W.last_ms = 0.0;
     return ret;
   }
-  // this frame's joint matrices
+  // this frame's joint matrices: the per-frame arguments are checked against the static description on every call (a
+  // direct C-ABI caller may hand anything): the skin table must be the one the geometries' skin indices were checked against
+  if (f->n_skins != W.n_skins) return fail(c, RT_ERR_INVALID, "rt_world_update: the number of skins changed under an unchanged static_epoch");
+  if (f->n_skins && !f->skin_first) return fail(c, RT_ERR_INVALID, "rt_world_update: null skin table");
+  for (uint32_t k = 0; k < f->n_skins; k++)
+    if (f->skin_first[k + 1] < f->skin_first[k]) return fail(c, RT_ERR_INVALID, "rt_world_update: the skin table is not non-decreasing");
+  if (f->n_skins && f->skin_first[0] != 0u) return fail(c, RT_ERR_INVALID, "rt_world_update: the skin table does not start at joint 0");
   const uint32_t n_joints = f->n_skins ? f->skin_first[f->n_skins] : 0u;
   if (n_joints && !f->joint_mats) return fail(c, RT_ERR_INVALID, "rt_world_update: null joint matrices");
   const size_t joint_bytes = (size_t)n_joints * 64;
@@ -1111,6 +1135,7 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
   uint32_t* d_stats = (uint32_t*)W.stats.ptr;
   float4* nodes = (float4*)c->nodes.ptr;
   for (int attempt = 0;; attempt++) {
+    *touched = true;   // from here on the live scene buffers are being rewritten
     HIP_TRY(c, hipEventRecord(W.ev0, c->stream));
     if (joint_bytes) {
       std::memcpy(pinned_joints, f->joint_mats, joint_bytes);
@@ -1154,7 +1179,20 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     A.nodes = nodes;
     A.inst_out = (float4*)c->instances.ptr;
     A.draw_out = (uint4*)c->draw_commands.ptr;
-    hipLaunchKernelGGL(wu::k_tlas, dim3(1), dim3(1024), 0, c->stream, A);
+    {
+      uint32_t m = 1024u;
+      while (m < N) m <<= 1;
+      if (!W.tlas_lds_set) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)wu::k_tlas, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RT_TLAS_MAX_INSTANCES * 8u)));
+        W.tlas_lds_set = true;
+      }
+      HIP_TRY(c, hipEventRecord(W.ev_t0, c->stream));
+      if (N <= 1024u && !getenv("MI355RT_TLAS_GENERIC"))   // one position per lane, everything in LDS / registers (config 3: 1 001)
+        hipLaunchKernelGGL(wu::k_tlas_small, dim3(1), dim3(1024), 0, c->stream, A);
+      else
+        hipLaunchKernelGGL(wu::k_tlas, dim3(1), dim3(1024), (size_t)m * 8, c->stream, A);
+      HIP_TRY(c, hipEventRecord(W.ev_t1, c->stream));
+    }
     if (W.n_lights)
       hipLaunchKernelGGL(wu::k_lights, dim3(N), dim3(256), 0, c->stream, A, (const uint32_t*)W.em_list.ptr, (uint2*)c->lights.ptr);
     HIP_TRY(c, hipGetLastError());
@@ -1191,6 +1229,7 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     if (rb_status[1] != W.n_lights) return fail(c, RT_ERR_INTERNAL, "rt_world_update: light count mismatch");
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, W.ev0, W.ev1) == hipSuccess) W.last_ms = ms;
+    if (hipEventElapsedTime(&ms, W.ev_t0, W.ev_t1) == hipSuccess) W.last_tlas_ms = ms;
     // ---- host bookkeeping, what rt_upload / rt_upload_geometry / rt_upload_bvh would have set
     const uint32_t n_blas = rb_base[G];
     c->n_verts = c->vertex_count = W.n_verts;
@@ -1234,6 +1273,7 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
     HIP_TRY(c, hipMemcpyAsync(c->val_roots.ptr, c->blas_roots.data(), c->blas_roots.size() * 4, hipMemcpyHostToDevice, c->stream));
     c->validate_dirty = false;
     c->scene_valid = true;
+    c->nodes_from_device = true;
     c->tris_dirty = c->inst_dirty = c->lights_dirty = c->nodes_dirty = c->pairs_dirty = c->roots_dirty = true;
     if (W.cache_enabled && !W.static_cached) {   // first full update of this description: keep the static geometries' node blocks
       W.static_count.assign(G, 0u);
@@ -1257,7 +1297,29 @@ int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
   }
 }
 
+int rt_world_update(rt_ctx* c, const rt_world_frame* f) {
+  if (!c || !f) return RT_ERR_INVALID;
+  bool touched = false;
+  const int r = world_update_body(c, f, &touched);
+  if (r < 0 && touched) {
+    // The update writes straight into the live scene buffers (positions, topology, nodes, instances, lights).  A failure
+    // after its first kernel leaves a mix of two scenes there, with the counts and the derived records of the old one:
+    // nothing may be traced from it.  compute() refuses until the scene has been uploaded again (rt_upload* re-validates);
+    // the Python / Node bridges do exactly that (the scene compiler then runs this update on the host).
+    const std::string why = c->error;
+    c->scene_valid = false;
+    c->validate_dirty = false;
+    c->scene_problem = "the device-resident world update failed part-way (" + why + "): the scene buffers hold a mix of two scenes; upload the scene again";
+    c->tris_dirty = c->inst_dirty = c->lights_dirty = c->nodes_dirty = c->pairs_dirty = c->roots_dirty = true;
+    c->world.static_cached = false;
+    c->world.valid = false;
+    c->error = why;
+  }
+  return r;
+}
+
 double rt_world_last_ms(const rt_ctx* c) { return c ? c->world.last_ms : 0.0; }
+double rt_world_last_tlas_ms(const rt_ctx* c) { return c ? c->world.last_tlas_ms : 0.0; }
 
 int rt_world_set_static_cache(rt_ctx* c, int enabled) {
   if (!c) return RT_ERR_INVALID;
@@ -1434,6 +1496,7 @@ int rt_upload_bvh(rt_ctx* c, const float* tlas, uint32_t n_tlas, const float* bl
   c->validate_dirty = true;
   c->nodes_dirty = true;
   c->pairs_dirty = true;
+  c->nodes_from_device = false;
   return r ? RT_REALLOCATED : RT_OK;
 }
 

@@ -649,7 +649,11 @@ ObjMesh octahedron_mesh() {  // same shape as public/diamond.obj (6 vertices, 8 
 
 // Config 3: Cornell shell (instance 0) + 10x10x10 lattice of octahedra sharing
 // three BLASes (Lambert / metal 0.2 / dielectric 1.5), scale 0.06, rotY(0.37 i).
-SceneData scene_instanced1000() {
+// The same with nx x ny x nz octahedra (minus `skip` at the end): instanced16384 = the Cornell shell + 16 383 of a
+// 32 x 32 x 16 lattice = the 16 384 instances the device TLAS takes (a scale test of World::update's TLAS, not a BASELINE config).
+SceneData scene_instanced_lattice(int nx, int ny, int nz, int skip, float scale);
+SceneData scene_instanced1000() { return scene_instanced_lattice(10, 10, 10, 0, 0.06f); }
+SceneData scene_instanced_lattice(int nx, int ny, int nz, int skip, float scale) {
   SceneData sd;
   Geometry env;
   add_cornell_shell(env, CornellStyle{LAMBERTIAN, 0.0f, v3(20, 20, 20), 213, 227, 343, 332});
@@ -664,13 +668,17 @@ SceneData scene_instanced1000() {
     sd.geometries.push_back(std::move(g));
   }
   sd.instances.push_back(SceneInstance{m4_identity(), 0});
+  // (10 x 10 x 10: the literal spacing 0.18 and origin of round 1, so that config 3's arrays do not change by a bit)
+  const float dx = nx == 10 ? 0.18f : 1.8f / (float)nx, dy = ny == 10 ? 0.18f : 1.8f / (float)ny, dz = nz == 10 ? 0.18f : 1.8f / (float)nz;
+  const float x0 = nx == 10 ? -0.81f : -0.9f + 0.5f * dx, y0 = ny == 10 ? 0.19f : 0.1f + 0.5f * dy, z0 = nz == 10 ? -0.81f : -0.9f + 0.5f * dz;
+  const int total = nx * ny * nz - skip;
   int i = 0;
-  for (int iz = 0; iz < 10; iz++)
-    for (int iy = 0; iy < 10; iy++)
-      for (int ix = 0; ix < 10; ix++, i++) {
-        V3 p = v3(-0.81f + 0.18f * (float)ix, 0.19f + 0.18f * (float)iy, -0.81f + 0.18f * (float)iz);
+  for (int iz = 0; iz < nz; iz++)
+    for (int iy = 0; iy < ny; iy++)
+      for (int ix = 0; ix < nx && i < total; ix++, i++) {
+        V3 p = v3(x0 + dx * (float)ix, y0 + dy * (float)iy, z0 + dz * (float)iz);
         M4 t = m4_mul(m4_from_translation(p),
-                      m4_mul(m4_from_rotation_y(0.37f * (float)i), m4_from_scale(v3(0.06f, 0.06f, 0.06f))));
+                      m4_mul(m4_from_rotation_y(0.37f * (float)i), m4_from_scale(v3(scale, scale, scale))));
         sd.instances.push_back(SceneInstance{t, (size_t)(1 + i % 3)});
       }
   sd.camera = CameraConfig{v3(0, 1, -2.4f), v3(0, 1, 0), v3(0, 1, 0), 60.0f, 0.0f, 2.4f};
@@ -1604,6 +1612,8 @@ ms_world* ms_world_create_glb(const char* scene_name, const char* obj_source, co
     w->scene = scene_viewer(has_mesh ? &mesh : nullptr, has_glb);
   } else if (name == "instanced1000") {
     w->scene = scene_instanced1000();
+  } else if (name == "instanced16384") {
+    w->scene = scene_instanced_lattice(32, 32, 16, 1, 0.02f);
   } else if (name == "sponza_like") {
     w->scene = scene_sponza_like();
   } else if (name == "glass_blob") {

@@ -177,7 +177,7 @@ def load_library(path=None):
         "rt_set_kernel_variant": (i32, [vp, i32]), "rt_set_walk": (i32, [vp, i32]), "rt_set_lookahead": (i32, [vp, u32]),
         "rt_set_lookahead_limit": (i32, [vp, u32]),
         "rt_build_blas_levels": (i32, [vp]),
-        "rt_world_update": (i32, [vp, vp]), "rt_world_set_static_cache": (i32, [vp, i32]), "rt_world_last_ms": (ctypes.c_double, [vp]),
+        "rt_world_update": (i32, [vp, vp]), "rt_world_set_static_cache": (i32, [vp, i32]), "rt_world_last_ms": (ctypes.c_double, [vp]), "rt_world_last_tlas_ms": (ctypes.c_double, [vp]),
         "rt_world_read": (i32, [vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     }
     for name, (res, args) in sigs.items():
@@ -197,7 +197,7 @@ EXPORTED_SYMBOLS = (
     "rt_get_kernel_counters rt_bind_accum rt_bind_present_source rt_kernel_times rt_debug_clock_stamps rt_debug_trace_sections rt_debug_pt_sections rt_debug_lane_stats rt_debug_read_traversal_nodes rt_debug_read_pairs rt_debug_ieee_check "
     "rt_reset_counters rt_set_counting rt_set_stripes rt_accum_device_ptr rt_set_stream rt_kernel_time_ms "
     "rt_set_kernel_timing rt_device_count rt_set_kernel_variant rt_set_walk rt_set_lookahead "
-    "rt_world_update rt_world_last_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit rt_world_set_static_cache").split()
+    "rt_world_update rt_world_last_ms rt_world_last_tlas_ms rt_world_read rt_build_blas_levels rt_set_lookahead_limit rt_world_set_static_cache").split()
 
 
 def _ptr(a):
@@ -315,6 +315,10 @@ class WebGPURenderer:
     def worldLastMs(self):
         """GPU stream time of the last device-resident update(t) (ms)."""
         return float(self.L.rt_world_last_ms(self.ctx))
+
+    def worldLastTlasMs(self):
+        """... of its TLAS kernel alone (ms)."""
+        return float(self.L.rt_world_last_tlas_ms(self.ctx))
 
     def readTextureLayer(self, layer):
         out = np.empty((1024, 1024, 4), dtype=np.uint8)
