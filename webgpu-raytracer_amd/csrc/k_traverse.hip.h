@@ -171,18 +171,40 @@ __device__ unsigned long long g_lane_stats[32];
 #define RT_LSTAT(k, cond) ((void)0)
 #endif
 
-struct Trav {  // one ray's traversal state
+// One ray's traversal state.  Everything a lane needs to know about itself is a 32-bit word in a VGPR and every question the
+// walk asks ("does this lane step?", "is it at the end of its array?", "does it wait for its leaf?") is ONE compare of such a
+// word, which the hardware answers as a lane mask in SGPRs.  (Round 4: until then the state was a set of bools — searching,
+// waiting, in_blas, entering, any.  The compiler keeps a bool that is live across divergent control flow as a lane mask and
+// merges it at every join with three scalar instructions, or as a 0 / 1 VGPR that each use turns back into a mask with two
+// more; a node step was 63 instructions of which 24 are the slab test.)
+//   curr       the node to test next, or RT_CURR_END (the successor field of a node that ends its array), RT_CURR_ENTER (mixed
+//              mode: the lane hit a TLAS leaf and waits for its instance transform), RT_CURR_IDLE (the lane does not search:
+//              it waits for the triangles of a leaf, has finished, or never had a ray)
+//   leaf       0, or the leaf word (first triangle << 3 | count, count >= 1) of the BLAS leaf whose triangles the lane waits for
+//   resume     while waiting: the node to go on with
+//   tlas_next  RT_TLAS_NONE while the lane walks the TLAS; inside an instance the successor of the TLAS leaf (a node or
+//              RT_NODE_END)
+//   best_tri   -1 until a hit is recorded; an any-hit ray records its first accepted triangle, which is all `occluded` needs
+#define RT_CURR_END RT_NODE_END
+#define RT_CURR_IDLE 0xfffffffeu
+#define RT_CURR_ENTER 0xfffffffdu
+#define RT_TLAS_NONE 0xfffffffeu
+struct Trav {
   LocalRay r;                // the ray in the space it is currently walking (world or instance)
   LocalRay rw;               // the world-space ray (rw.o, rw.d = the ray as given)
   float closest;             // t_min is the constant RT_T_MIN for every ray of the reference (Raytracer.wgsl:6,688,732)
   int32_t best_tri, best_inst;
-  uint32_t curr, tlas_next, cur_inst, leaf;
-  bool searching, waiting, in_blas, any;
-  bool entering;             // mixed mode: hit a TLAS leaf, instance entry pending (still `searching`)
+  uint32_t curr, tlas_next, cur_inst, leaf, resume;
 #ifdef RT_LANE_STATS
   uint32_t stat_kind;        // 1 = shadow walk, 3 = extension walk (RT_LSTAT part of its node steps; + 1 = its triangle chunks)
 #endif
 };
+__device__ __forceinline__ bool trav_stepping(const Trav& s) { return s.curr < RT_CURR_ENTER; }   // takes node steps
+__device__ __forceinline__ bool trav_searching(const Trav& s) { return s.curr != RT_CURR_IDLE; }  // ... or is about to
+__device__ __forceinline__ bool trav_waiting(const Trav& s) { return s.leaf != 0u; }
+__device__ __forceinline__ bool trav_entering(const Trav& s) { return s.curr == RT_CURR_ENTER; }
+__device__ __forceinline__ bool trav_busy(const Trav& s) { return (s.curr != RT_CURR_IDLE) | (s.leaf != 0u); }
+__device__ __forceinline__ bool trav_any(const Trav& s) { return s.best_tri != -1; }
 
 __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_base, rt3 o, rt3 d, float t_max) {
   s.rw = make_ray(o, d);
@@ -190,90 +212,84 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
   s.closest = t_max;
   s.best_tri = -1;
   s.best_inst = -1;
-  s.curr = 0u;               // the TLAS root is node 0 of tnodes
-  s.tlas_next = RT_NODE_END;
+  s.curr = (active && blas_base != 0u) ? 0u : RT_CURR_IDLE;   // the TLAS root is node 0 of tnodes
+  s.tlas_next = RT_TLAS_NONE;
   s.cur_inst = 0u;
   s.leaf = 0u;
-  s.searching = active && blas_base != 0u;
-  s.waiting = false;
-  s.in_blas = false;
-  s.any = false;
-  s.entering = false;
+  s.resume = 0u;
 #ifdef RT_LANE_STATS
   s.stat_kind = 1u;
 #endif
 }
 
-// the walk ran off its array (rare): leave the instance (back to the world-space ray and the TLAS cursor), or finish.
-// Written as selects behind a wave-uniform test: as a per-lane branch that recomputes the ray, the twelve registers of
-// the ray were copied out and back on EVERY trip to merge the two paths.
+// the walk ran off its array: leave the instance (back to the world-space ray and the TLAS cursor), or finish.  Behind
+// wave-uniform tests: the twelve selects that restore the ray only run when some lane really goes back to a TLAS node (as a
+// per-lane branch the ray's registers were copied out and back on every trip to merge the two paths).
 __device__ __forceinline__ void trav_leave(Trav& s) {
-  const bool at_end = s.searching && s.curr == RT_NODE_END;
-  if (__ballot(at_end) != 0ull) {
-    const bool leave = at_end && s.in_blas && s.tlas_next != RT_NODE_END;
-    s.r.o.x = leave ? s.rw.o.x : s.r.o.x; s.r.o.y = leave ? s.rw.o.y : s.r.o.y; s.r.o.z = leave ? s.rw.o.z : s.r.o.z;
-    s.r.d.x = leave ? s.rw.d.x : s.r.d.x; s.r.d.y = leave ? s.rw.d.y : s.r.d.y; s.r.d.z = leave ? s.rw.d.z : s.r.d.z;
-    s.r.inv_d.x = leave ? s.rw.inv_d.x : s.r.inv_d.x; s.r.inv_d.y = leave ? s.rw.inv_d.y : s.r.inv_d.y;
-    s.r.inv_d.z = leave ? s.rw.inv_d.z : s.r.inv_d.z;
-    s.r.o_inv_d.x = leave ? s.rw.o_inv_d.x : s.r.o_inv_d.x; s.r.o_inv_d.y = leave ? s.rw.o_inv_d.y : s.r.o_inv_d.y;
-    s.r.o_inv_d.z = leave ? s.rw.o_inv_d.z : s.r.o_inv_d.z;
-    s.curr = leave ? s.tlas_next : s.curr;
-    s.in_blas = s.in_blas && !leave;
-    s.searching = s.searching && (!at_end || leave);
+  const bool at_end = s.curr == RT_CURR_END;
+  if (__builtin_amdgcn_ballot_w64(at_end) != 0ull) {
+    const bool leave = at_end & (s.tlas_next < RT_TLAS_NONE);   // inside an instance whose TLAS leaf has a successor
+    if (__builtin_amdgcn_ballot_w64(leave) != 0ull) {
+      s.r.o.x = leave ? s.rw.o.x : s.r.o.x; s.r.o.y = leave ? s.rw.o.y : s.r.o.y; s.r.o.z = leave ? s.rw.o.z : s.r.o.z;
+      s.r.d.x = leave ? s.rw.d.x : s.r.d.x; s.r.d.y = leave ? s.rw.d.y : s.r.d.y; s.r.d.z = leave ? s.rw.d.z : s.r.d.z;
+      s.r.inv_d.x = leave ? s.rw.inv_d.x : s.r.inv_d.x; s.r.inv_d.y = leave ? s.rw.inv_d.y : s.r.inv_d.y;
+      s.r.inv_d.z = leave ? s.rw.inv_d.z : s.r.inv_d.z;
+      s.r.o_inv_d.x = leave ? s.rw.o_inv_d.x : s.r.o_inv_d.x; s.r.o_inv_d.y = leave ? s.rw.o_inv_d.y : s.r.o_inv_d.y;
+      s.r.o_inv_d.z = leave ? s.rw.o_inv_d.z : s.r.o_inv_d.z;
+    }
+    s.curr = leave ? s.tlas_next : (at_end ? RT_CURR_IDLE : s.curr);
+    s.tlas_next = leave ? RT_TLAS_NONE : s.tlas_next;
   }
 }
 
 // instance entry of the lanes that hit a TLAS leaf (deferred form): object-space ray, BLAS root
 template <int MODE>
 __device__ __forceinline__ void trav_enter(const TravMem& M, const f4* lds, Trav& s) {
-  if (s.entering) {
+  if (trav_entering(s)) {
     uint32_t root;
     s.r = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
     s.curr = root;
-    s.in_blas = true;
-    s.entering = false;
   }
 }
 
 // what a lane does with the node record it fetched (Raytracer.wgsl:462-473, 498-518): slab test against the current
-// bound, successor, leaf bookkeeping.  DEFER: a TLAS-leaf hit only marks the lane as `entering` (trav_enter does the
-// transform later, for many lanes at once); otherwise the instance is entered on the spot.
+// bound, successor, leaf bookkeeping.  DEFER: a TLAS-leaf hit only parks the lane as RT_CURR_ENTER (trav_enter does the
+// transform later, for many lanes at once); otherwise the instance is entered on the spot.  Only stepping lanes come here,
+// and a stepping lane has leaf == 0.
 template <bool COUNT, int MODE, bool DEFER>
 __device__ __forceinline__ void trav_node(const TravMem& M, const f4* lds, Trav& s, f4 lo, f4 hi, uint32_t& n_nodes) {
   if (COUNT) n_nodes++;
   const bool hit = hit_box4(lo, hi, s.r, RT_T_MIN, s.closest);
   const uint32_t data = rt_f2u(hi.w);
   const bool inner = (data & RT_NODE_INNER) != 0u;
-  const bool leafhit = hit && !inner;
-  uint32_t next = (hit && inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
-  const bool got_leaf = leafhit && s.in_blas;
-  if (leafhit && !s.in_blas) {  // TLAS leaf: enter the instance
+  const bool leafhit = hit & !inner;
+  uint32_t next = (hit & inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
+  const bool in_tlas = s.tlas_next == RT_TLAS_NONE;
+  const bool got_leaf = leafhit & !in_tlas;
+  if (leafhit & in_tlas) {  // TLAS leaf: enter the instance
     s.cur_inst = data >> 3;
     s.tlas_next = next;
     if (DEFER) {
-      s.entering = true;
-      next = 0u;   // any node but RT_NODE_END: trav_leave must not take the lane for one that ran off its array
+      next = RT_CURR_ENTER;
     } else {
       uint32_t root;
       s.r = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
       next = root;
-      s.in_blas = true;
     }
   }
-  s.leaf = got_leaf ? data : s.leaf;
-  s.waiting = got_leaf;
-  s.searching = !got_leaf;
-  s.curr = next;
+  s.leaf = got_leaf ? data : 0u;
+  s.resume = got_leaf ? next : s.resume;
+  s.curr = got_leaf ? RT_CURR_IDLE : next;
 }
 
-// one node step for every searching lane; select-based, two branches only
+// one node step for every stepping lane; select-based, two branches only
 template <bool COUNT, int MODE>
 __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, Trav& s, uint32_t& n_nodes) {
   trav_leave(s);
 #ifdef RT_LANE_STATS
-  RT_LSTAT(s.stat_kind, s.searching);
+  RT_LSTAT(s.stat_kind, trav_stepping(s));
 #endif
-  if (s.searching) {
+  if (trav_stepping(s)) {
     f4 lo, hi;
     trav_fetch_node<MODE>(M, lds, s.curr, lo, hi);
     trav_node<COUNT, MODE, false>(M, lds, s, lo, hi, n_nodes);
@@ -308,12 +324,12 @@ __device__ __forceinline__ void trav_trip_mixed(const TravMem& M, const f4* lds,
   for (int k = 0; k < ROUNDS; k++) {
     trav_leave(s);
     {
-      const unsigned long long em = __ballot(s.entering);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(trav_entering(s));
       if (em != 0ull && (inst_lds || (uint32_t)__builtin_popcountll(em) >= RT_ENTER_BATCH ||
-                         __ballot(s.searching && !s.entering) == 0ull))
+                         __builtin_amdgcn_ballot_w64(trav_stepping(s)) == 0ull))   // after trav_leave no lane is at an end
         trav_enter<MODE>(M, lds, s);
     }
-    const bool g = s.searching && !s.entering && s.curr >= M.k_lds;
+    const bool g = trav_stepping(s) & (s.curr >= M.k_lds);
     f4 glo, ghi;
     if (g) {
       glo = ld_g(M.gnodes, 2 * (size_t)s.curr);
@@ -322,9 +338,9 @@ __device__ __forceinline__ void trav_trip_mixed(const TravMem& M, const f4* lds,
     if (M.k_lds != 0u) {
 #pragma unroll 1
       for (int j = 0; j < RT_LDS_SUBSTEPS; j++) {
-        if (inst_lds && __ballot(s.entering) != 0ull) trav_enter<MODE>(M, lds, s);
-        const bool l = s.searching && !s.entering && !g && s.curr < M.k_lds;   // RT_NODE_END is never < k_lds
-        if (__ballot(l) == 0ull) break;
+        if (inst_lds && __builtin_amdgcn_ballot_w64(trav_entering(s)) != 0ull) trav_enter<MODE>(M, lds, s);
+        const bool l = s.curr < M.k_lds;   // no special value of curr is < k_lds, and a lane with a load in flight is at a global node
+        if (__builtin_amdgcn_ballot_w64(l) == 0ull) break;
         if (l) {
           const f4 lo = ld_l(lds, M.l_nodes + 2u * s.curr), hi = ld_l(lds, M.l_nodes + 2u * s.curr + 1u);
           trav_node<COUNT, MODE, true>(M, lds, s, lo, hi, n_nodes);
@@ -352,11 +368,12 @@ __device__ __forceinline__ void trav_trip(const TravMem& M, const f4* lds, Trav&
 template <bool ANY, bool COUNT, int MODE>
 __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s, uint32_t& n_tris) {
   const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long smask = __ballot(s.searching);
-  const unsigned long long wmask = __ballot(s.waiting);
+  const unsigned long long smask = __builtin_amdgcn_ballot_w64(trav_searching(s));
+  const bool waiting = trav_waiting(s);
+  const unsigned long long wmask = __builtin_amdgcn_ballot_w64(waiting);
   if ((smask | wmask) == 0ull) return false;
   if (wmask == 0ull) return true;
-  const uint32_t cnt = s.waiting ? (s.leaf & 7u) : 0u;
+  const uint32_t cnt = s.leaf & 7u;   // 0 for a lane that does not wait
   const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
   const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
                          4u * (uint32_t)__builtin_popcountll(b2);
@@ -366,7 +383,7 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
       2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
       4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
   const uint32_t first = s.leaf >> 3;
-  if (s.waiting) {
+  if (waiting) {
     f4 ra, rb;
     ra.x = rt_opaque(s.r.o.x); ra.y = rt_opaque(s.r.o.y); ra.z = rt_opaque(s.r.o.z); ra.w = RT_T_MIN;
     rb.x = rt_opaque(s.r.d.x); rb.y = rt_opaque(s.r.d.y); rb.z = rt_opaque(s.r.d.z); rb.w = s.closest;
@@ -381,7 +398,7 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
   // leaves of the reference's builder hold <= 4 triangles (blas.rs:99); only its fallback leaves hold 5-7: those three
   // stores sit behind a wave-uniform test (count bit 2 set together with bit 0 or bit 1)
   if ((b2 & (b0 | b1)) != 0ull) {
-    if (s.waiting) {
+    if (waiting) {
       const uint32_t tag = lane << 26;
 #pragma unroll
       for (uint32_t i = 4; i < 7u; i++)
@@ -422,21 +439,19 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (s.waiting) {
+  if (waiting) {
     const unsigned long long best = W.res[lane];
     const bool found = best != ~0ull;
     if (COUNT) n_tris += (ANY && found) ? ((uint32_t)best - first + 1u) : cnt;   // the any-hit loop stops at its first hit
     if (found) {
-      if (ANY) {
-        s.any = true;
-      } else {
+      s.best_tri = (int32_t)(uint32_t)best;
+      if (!ANY) {
         s.closest = rt_u2f((uint32_t)(best >> 32));
-        s.best_tri = (int32_t)(uint32_t)best;
         s.best_inst = (int32_t)s.cur_inst;
       }
     }
-    s.waiting = false;
-    s.searching = !(ANY && found);
+    s.leaf = 0u;
+    s.curr = (ANY && found) ? RT_CURR_IDLE : s.resume;
   }
   __builtin_amdgcn_wave_barrier();
   return true;
@@ -461,7 +476,7 @@ __device__ __forceinline__ void traverse(const TravMem& M, const f4* lds, const 
   out_t = s.closest;
   out_tri = s.best_tri;
   out_inst = s.best_inst;
-  out_any = s.any;
+  out_any = trav_any(s);
 }
 
 }  // namespace rtk

@@ -299,10 +299,10 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     st_trips++;
 #endif
     // ---- retire finished rays and pull new ones (batched: a block that runs for one lane costs as much as for 64)
-    const bool done = have_ray && !s.searching && !s.waiting;
+    const bool done = have_ray && !trav_busy(s);
     const bool idle = !have_ray || done;
     const unsigned long long idle_m = __ballot(idle), done_m = __ballot(done);
-    const unsigned long long busy_m = __ballot(s.searching || s.waiting);
+    const unsigned long long busy_m = __ballot(trav_busy(s));
     if (idle_m != 0ull &&
         ((uint32_t)__builtin_popcountll(done_m) >= RT_WF_REFILL ||
          (queue_left && (uint32_t)__builtin_popcountll(idle_m) >= RT_WF_REFILL) || busy_m == 0ull)) {
@@ -311,7 +311,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
 #endif
       if (done) {
         if (ANY)
-          Q.occluded[slot] = s.any ? 1u : 0u;
+          Q.occluded[slot] = trav_any(s) ? 1u : 0u;
         else
           Q.ext_hit[slot] = make_float4(s.closest, rt_u2f((uint32_t)s.best_tri), rt_u2f((uint32_t)s.best_inst), 0.0f);
         have_ray = false;
@@ -352,20 +352,20 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     st_cyc[0] += st1 - st0;
-    if (__ballot(s.searching) != 0ull) st_cnt[1]++;
+    if (__ballot(trav_searching(s)) != 0ull) st_cnt[1]++;
 #endif
     trav_trip<DETAIL, MODE, RT_WF_NODE_STEPS_PER_TRIP>(M, s_scene, s, n_nodes);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
     st_cyc[1] += st2 - st1;
-    const bool was_waiting = __ballot(s.waiting) != 0ull;
+    const bool was_waiting = __ballot(trav_waiting(s)) != 0ull;
 #endif
     trav_flush<ANY, DETAIL, MODE>(M, s_scene, W, s, n_tris);
 #ifdef RT_TRACE_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     st_cyc[2] += __builtin_amdgcn_s_memtime() - st2;
-    if (was_waiting && __ballot(s.waiting) == 0ull) st_cnt[2]++;
+    if (was_waiting && __ballot(trav_waiting(s)) == 0ull) st_cnt[2]++;
 #endif
   }
 #ifdef RT_TRACE_STAMPS
