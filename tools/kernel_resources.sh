@@ -9,7 +9,7 @@ for line in sys.stdin:
     t = m.group(1).strip()
     if t.startswith("Function Name:"):
         name = t.split(":", 1)[1].strip()
-        try: name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        try: name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
         except Exception: pass
         cur = {"name": re.sub(r"\(.*", "", name).replace("void ", "")}; rows.append(cur)
     elif cur is not None and ":" in t:
