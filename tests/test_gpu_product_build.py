@@ -2,8 +2,7 @@
 
 Most parity tests run the counting variant (`setCounting(True)`), because `nodes_visited` / `tris_tested` pin the walk
 step by step.  The variants without those counters are separate template instances and, since round 4, take code the
-counting ones do not: shadow rays do not wait for their triangle tests (`trav_any_*`, csrc/k_traverse.hip.h) and the
-division / square-root expansions are the short sequences of csrc/k_ieee.hip.h.  These tests put every scene, kernel form
+counting ones do not: the division / square-root expansions are the short sequences of csrc/k_ieee.hip.h.  These tests put every scene, kernel form
 and record location (LDS / global memory) through exactly that code: accumulation buffer, G-buffer, presented image,
 history and the three ray counters must equal the oracle's.
 """
@@ -71,10 +70,14 @@ def test_product_build_parity(W, oracle_lib, gpu_renderer, scene, w, h, depth, s
 
 @pytest.mark.parametrize("scene,variant", [("cornell", 1), ("cornell", 2), ("mesh", 2), ("special", 1), ("special", 2), ("mixed", 2),
                                            ("viewer_diamond", 1)])
-def test_product_build_global_paths_on_small_scenes(W, oracle_lib, monkeypatch, scene, variant):
+@pytest.mark.parametrize("rayreg", ["0", "1"])
+def test_product_build_global_paths_on_small_scenes(W, oracle_lib, monkeypatch, scene, variant, rayreg):
     """MI355RT_NO_LDS_STAGING=1: the records of a small scene read through the L1 — the mixed-mode walk with deferred
-    instance entry that the large configs take, on scenes the oracle renders whole in seconds."""
+    instance entry that the large configs take, on scenes the oracle renders whole in seconds; both forms of the trace kernels."""
+    if variant == 1 and rayreg == "1":
+        pytest.skip("the persistent kernel has one form")
     monkeypatch.setenv("MI355RT_NO_LDS_STAGING", "1")
+    monkeypatch.setenv("MI355RT_WF_RAYREG", rayreg)
     b = pu.bridge_for(W, scene)
     w, h, depth, frames = 72, 48, 8, (1, 2, 3, 4)
     cpu = oracle_lib.OracleRenderer()
@@ -85,10 +88,14 @@ def test_product_build_global_paths_on_small_scenes(W, oracle_lib, monkeypatch, 
     r.destroy()
 
 
+@pytest.mark.parametrize("rayreg", ["0", "1"])
 @pytest.mark.parametrize("treelet", [64, 1000])
-def test_product_build_partial_node_staging(W, oracle_lib, monkeypatch, treelet):
-    """Part of the nodes in LDS, the rest behind the L1 (MI355RT_TREELET_MAX): the phased trip of the no-wait shadow walk."""
+def test_product_build_partial_node_staging(W, oracle_lib, monkeypatch, treelet, rayreg):
+    """Part of the nodes in LDS, the rest behind the L1 (MI355RT_TREELET_MAX): the phased trip of the mixed-mode walk, in both
+    forms of the trace kernels (MI355RT_WF_RAYREG: instance-space origin / direction posted to LDS at instance entry, or kept
+    in registers and posted with every flush — the host picks by instance count, csrc/k_traverse.hip.h trav_post_at_entry)."""
     monkeypatch.setenv("MI355RT_TREELET_MAX", str(treelet))
+    monkeypatch.setenv("MI355RT_WF_RAYREG", rayreg)
     b = pu.bridge_for(W, "instanced1000")
     w, h, depth, frames = 64, 40, 8, (1, 2, 3, 4)
     cpu = oracle_lib.OracleRenderer()

@@ -2,7 +2,7 @@
 """Where do the waves of k_wf_trace spend their cycles?  DIAGNOSTIC build (-DRT_TRACE_STAMPS): s_memtime around the three
 sections of the trace loop (retire / pull rays, node step, triangle flush), each closed by s_waitcnt 0 so that a
 section is charged for the memory it waits on.  Rebuilds the product library afterwards.
-usage: trace_sections.py [scene] [frames] [depth]"""
+usage: trace_sections.py [scene] [frames] [depth] [width] [height]"""
 import ctypes
 import os
 import sys
@@ -15,13 +15,15 @@ import webgpu_raytracer_amd as W  # noqa: E402
 scene = sys.argv[1] if len(sys.argv) > 1 else "sponza_like"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+width = int(sys.argv[4]) if len(sys.argv) > 4 else 1920
+height = int(sys.argv[5]) if len(sys.argv) > 5 else 1080
 W._build.build_rt(force=True, extra_flags=["-DRT_TRACE_STAMPS"])
 try:
     b = W.WorldBridge()
     b.loadScene(scene)
     r = W.WebGPURenderer(0)
     r.buildPipeline(depth, 1)
-    W.upload_scene(r, b, 1920, 1080)
+    W.upload_scene(r, b, width, height)
     fl = list(range(1, frames + 1))
     r.computeBatch(fl)
     r.sync()

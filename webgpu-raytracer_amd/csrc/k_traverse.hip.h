@@ -50,7 +50,9 @@ struct TravMem {
 
 // MODE_LDS: every record is in LDS (the whole scene fits: k_lds >= n_nodes and all l_* set) — the compiler sees plain
 // ds_read.  MODE_MIXED: per-access choice (a lane-level compare for nodes, wave-uniform flags for the rest).
-enum { RT_TRAV_LDS = 1, RT_TRAV_MIXED = 2 };
+// RT_TRAV_MIXED_RAYREG: mixed mode that keeps the instance-space origin / direction in registers and posts them with every
+// flush (trav_post_at_entry below).
+enum { RT_TRAV_LDS = 1, RT_TRAV_MIXED = 2, RT_TRAV_MIXED_RAYREG = 3 };
 
 template <int MODE>
 __device__ __forceinline__ void trav_fetch_node(const TravMem& M, const f4* lds, uint32_t idx, f4& lo, f4& hi) {
@@ -196,6 +198,7 @@ struct Trav {
                              // origin and direction of an instance-space ray live in LDS only (W.rays, posted at instance
                              // entry): the triangle tests read them there, the node steps never need them
   LocalRay rw;               // the world-space ray (rw.o, rw.d = the ray as given)
+  rt3 io, id;                // trav_post_at_entry() == false only: origin and direction of the instance-space ray
   float closest;             // t_min is the constant RT_T_MIN for every ray of the reference (Raytracer.wgsl:6,688,732)
   int32_t best_tri, best_inst;
   uint32_t curr, tlas_next, cur_inst, leaf, resume;
@@ -214,6 +217,8 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
   s.rw = make_ray(o, d);
   s.inv_d = s.rw.inv_d;
   s.o_inv_d = s.rw.o_inv_d;
+  s.io = o;                  // (never read before an instance entry sets them)
+  s.id = d;
   s.closest = t_max;
   s.best_tri = -1;
   s.best_inst = -1;
@@ -248,18 +253,31 @@ __device__ __forceinline__ void trav_leave(Trav& s) {
 // instance entry of one lane: the object-space ray (its origin and direction go to the lane's slot of W.rays, where the
 // triangle tests of this instance's leaves will read them; nothing of an earlier instance is still queued — a lane waits at
 // every leaf until its tests are done), returns the BLAS root
+// Where the origin and direction of the instance-space ray go: to the lane's slot of W.rays once, at instance entry (the walk
+// then carries six registers less and a flush writes 4 bytes per waiting lane instead of 32), or with every flush.
+// Measured on MI355X (ms per 32 frames, at entry / with every flush): Cornell (LDS mode) 21.1 / 21.3; in the trace kernels
+// instanced x1000 72.4 / 75.7 but glass blob 4K 306.2 / 292.1 — at 5, 6, 7 or 8 resident workgroups per CU alike, and with
+// the flush itself 40 % cheaper under section stamps (tools/exp/ab_sections.sh); the cause is not established.  So both forms
+// are compiled for the trace kernels and the host picks by scene (rt_api.hip: one instance = registers).
+template <int MODE>
+__device__ __forceinline__ constexpr bool trav_post_at_entry() { return MODE != RT_TRAV_MIXED_RAYREG; }
 template <int MODE>
 __device__ __forceinline__ uint32_t trav_into_instance(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s) {
   uint32_t root;
   const LocalRay q = to_instance<MODE>(M, lds, s.cur_inst, s.rw.o, s.rw.d, root);
   s.inv_d = q.inv_d;
   s.o_inv_d = q.o_inv_d;
-  const uint32_t lane = threadIdx.x & 63u;
-  f4 ra, rb;
-  ra.x = q.o.x; ra.y = q.o.y; ra.z = q.o.z; ra.w = 0.0f;   // .w: the bound at leaf entry, written by every flush
-  rb.x = q.d.x; rb.y = q.d.y; rb.z = q.d.z; rb.w = 0.0f;
-  W.rays[2 * lane] = ra;
-  W.rays[2 * lane + 1] = rb;
+  if (trav_post_at_entry<MODE>()) {
+    const uint32_t lane = threadIdx.x & 63u;
+    f4 ra, rb;
+    ra.x = q.o.x; ra.y = q.o.y; ra.z = q.o.z; ra.w = 0.0f;   // .w: the bound at leaf entry, written by every flush
+    rb.x = q.d.x; rb.y = q.d.y; rb.z = q.d.z; rb.w = 0.0f;
+    W.rays[2 * lane] = ra;
+    W.rays[2 * lane + 1] = rb;
+  } else {
+    s.io = q.o;
+    s.id = q.d;
+  }
   return root;
 }
 
@@ -332,9 +350,8 @@ __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, const
 #ifndef RT_ENTER_BATCH
 #define RT_ENTER_BATCH 16u
 #endif
-template <bool COUNT, int ROUNDS>
+template <bool COUNT, int MODE, int ROUNDS>
 __device__ __forceinline__ void trav_trip_mixed(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s, uint32_t& n_nodes) {
-  constexpr int MODE = RT_TRAV_MIXED;
   const bool inst_lds = M.l_inst != RT_LDS_NONE;   // wave-uniform
 #pragma unroll
   for (int k = 0; k < ROUNDS; k++) {
@@ -375,7 +392,7 @@ __device__ __forceinline__ void trav_trip(const TravMem& M, const f4* lds, const
 #pragma unroll
     for (int k = 0; k < STEPS; k++) trav_step<COUNT, MODE>(M, lds, W, s, n_nodes);
   } else {
-    trav_trip_mixed<COUNT, STEPS>(M, lds, W, s, n_nodes);
+    trav_trip_mixed<COUNT, MODE, STEPS>(M, lds, W, s, n_nodes);
   }
 }
 
@@ -395,7 +412,9 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
   if (wmask == 0ull) return smask != 0ull;
   // (one scalar select and one scalar compare: as `few waiting && some searching` the compiler builds lane masks for both)
   const uint32_t n_wait = smask != 0ull ? (uint32_t)__builtin_popcountll(wmask) : 64u;
+#ifndef RT_EXP_ITEMS24
   if (n_wait < RT_FLUSH_LANES) return true;
+#endif
   const uint32_t cnt = s.leaf & 7u;   // 0 for a lane that does not wait
   const unsigned long long b0 = __builtin_amdgcn_ballot_w64((cnt & 1u) != 0u), b1 = __builtin_amdgcn_ballot_w64((cnt & 2u) != 0u),
                            b2 = __builtin_amdgcn_ballot_w64((cnt & 4u) != 0u);
@@ -405,9 +424,20 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
       __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
       2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
       4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+#ifdef RT_EXP_ITEMS24
+  if (total < 24u && smask != 0ull) return true;
+#endif
   const uint32_t first = s.leaf >> 3;
   if (waiting) {
-    reinterpret_cast<float*>(W.rays)[8u * lane + 3u] = s.closest;   // the bound at leaf entry, beside the origin
+    if (trav_post_at_entry<MODE>()) {
+      reinterpret_cast<float*>(W.rays)[8u * lane + 3u] = s.closest;   // the bound at leaf entry, beside the origin
+    } else {
+      f4 ra, rb;
+      ra.x = rt_opaque(s.io.x); ra.y = rt_opaque(s.io.y); ra.z = rt_opaque(s.io.z); ra.w = s.closest;
+      rb.x = rt_opaque(s.id.x); rb.y = rt_opaque(s.id.y); rb.z = rt_opaque(s.id.z); rb.w = 0.0f;
+      W.rays[2 * lane] = ra;
+      W.rays[2 * lane + 1] = rb;
+    }
     W.res[lane] = ~0ull;
     // Items (owner lane << 26 | triangle) of the lane's leaf at [excl, excl + cnt).  Four UNCONDITIONAL stores, the highest
     // slot first: a store past the lane's count lands on slot j < i of a later lane (excl' >= excl + cnt), and that lane's own
@@ -416,10 +446,14 @@ __device__ __forceinline__ bool trav_flush(const TravMem& M, const f4* lds, cons
     // excl + 3 <= 63 * 7 + 3: inside the 448-entry queue.  Conditional stores cost a compare, an exec save and a branch each.
     const rt_lptr32_ordered it = (rt_lptr32_ordered)(W.items + excl);
     const uint32_t word = (lane << 26) | first;
+#ifdef RT_EXP_COND_STORES
+    for (uint32_t i = 0; i < 4u; i++) if (i < cnt) W.items[excl + i] = word + i;
+#else
     it[3] = word + 3u;
     it[2] = word + 2u;
     it[1] = word + 1u;
     it[0] = word;
+#endif
   }
   // leaves of the reference's builder hold <= 4 triangles (blas.rs:99); only its fallback leaves hold 5-7: those three
   // stores sit behind a wave-uniform test (count bit 2 set together with bit 0 or bit 1) and come after the four above

@@ -252,7 +252,8 @@ __device__ unsigned long long g_trace_sections[2][8];
 #ifndef RT_WF_NODE_STEPS_PER_TRIP
 #define RT_WF_NODE_STEPS_PER_TRIP 6
 #endif
-template <bool ANY, bool DETAIL, bool LDS, int BLOCK>
+// RAYREG (mixed mode only): the instance-space origin / direction stay in registers (RT_TRAV_MIXED_RAYREG, k_traverse.hip.h).
+template <bool ANY, bool DETAIL, bool LDS, int BLOCK, bool RAYREG = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? (LDS ? 4 : RT_WF_NODE_WAVES) : (BLOCK == 512 ? 2 : 4))
 void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32_t depth, uint32_t n_nodes_total,
                 uint32_t n_tris_total, uint32_t n_inst_total, LdsPlan plan) {
@@ -272,7 +273,7 @@ void k_wf_trace(DevScene Sg, DevFrame F, rt_scene_uniforms U, WfQueues Q, uint32
     trav_stage_mixed(M, s_scene, rec0, Sg, plan, n_tris_total, n_inst_total);
   }
   __syncthreads();
-  constexpr int MODE = LDS ? RT_TRAV_LDS : RT_TRAV_MIXED;
+  constexpr int MODE = LDS ? RT_TRAV_LDS : (RAYREG ? RT_TRAV_MIXED_RAYREG : RT_TRAV_MIXED);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t blas_base = U.blas_base_idx;
   uint32_t* cnt = Q.counters + 8u * depth;

@@ -136,6 +136,7 @@ struct rt_ctx {
                                  // (MI355RT_WALK): pairs for a scene of ONE instance (measured: the 263 k-triangle hall -9 % per
                                  // batch; glass blob, 2 instances and short walks: +7 %; 1 001 instances of 8 triangles: +20 %)
   int wf_blocks_per_cu = 0;      // 0 = default for the block size (MI355RT_WF_BLOCKS_PER_CU)
+  int wf_rayreg = -1;            // node-walk trace kernels: -1 = by scene, 0 / 1 = MI355RT_WF_RAYREG
   long treelet_cap = -1;
   int treelet_order = 2;          // order of tnodes: 0 = by visit probability, 1 = the bridge's depth-first order, 2 = auto (MI355RT_TREELET_ORDER)
   bool nodes_from_device = false; // the node array was made by rt_world_update (an animated world), not uploaded
@@ -560,6 +561,7 @@ rt_ctx* rt_create(int device_ordinal) {
   if (const char* e = getenv("MI355RT_TREELET_MAX")) c->treelet_cap = atol(e);
   if (const char* e = getenv("MI355RT_TREELET_ORDER")) c->treelet_order = e[0] == 'w' ? 0 : (e[0] == 'i' ? 1 : 2);
   if (const char* e = getenv("MI355RT_WALK")) c->walk = (e[0] == 'n' || e[0] == '0') ? 0 : ((e[0] == 'a' || e[0] == '2') ? 2 : 1);   // node / pairs / auto
+  if (const char* e = getenv("MI355RT_WF_RAYREG")) c->wf_rayreg = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("MI355RT_WF_BLOCKS_PER_CU")) {
     const int b = atoi(e);
     if (b >= 1 && b <= 8) c->wf_blocks_per_cu = b;
@@ -1578,7 +1580,11 @@ static rtk::PairPlan plan_pairs(const rt_ctx* c, size_t budget, size_t queue_byt
 
 extern "C++" {
 template <int BLOCK>
-static const void* wf_trace_fn(bool any, bool detail, bool lds) {
+static const void* wf_trace_fn(bool any, bool detail, bool lds, bool rayreg) {
+  if (BLOCK == 256 && rayreg && !lds) {   // instance-space ray in registers: compiled for the default workgroup size only
+    if (any) return detail ? (const void*)rtk::k_wf_trace<true, true, false, 256, true> : (const void*)rtk::k_wf_trace<true, false, false, 256, true>;
+    return detail ? (const void*)rtk::k_wf_trace<false, true, false, 256, true> : (const void*)rtk::k_wf_trace<false, false, false, 256, true>;
+  }
   if (any) {
     if (detail) return lds ? (const void*)rtk::k_wf_trace<true, true, true, BLOCK> : (const void*)rtk::k_wf_trace<true, true, false, BLOCK>;
     return lds ? (const void*)rtk::k_wf_trace<true, false, true, BLOCK> : (const void*)rtk::k_wf_trace<true, false, false, BLOCK>;
@@ -1692,10 +1698,14 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     nplan.stage_inst = nplan.stage_tri = 1;
     nplan.pad = 0;
     if (!trace_lds) nplan = plan_lds(c, c->lds_per_cu / (size_t)blocks_per_cu, queue_bytes, &dyn);
+    // few instances with deep trees (glass blob: 3 instances, 400 k nodes): a ray enters an instance once and then waits at
+    // many leaves; measured, the form that keeps its instance-space origin / direction in registers is the faster one there,
+    // the other one where rays enter many small instances (k_traverse.hip.h, trav_post_at_entry; MI355RT_WF_RAYREG=0/1 overrides)
+    const bool rayreg = c->wf_rayreg < 0 ? (size_t)c->n_nodes >= (size_t)1024 * std::max<size_t>(1, c->n_instances) : c->wf_rayreg != 0;
     for (int k = 0; k < 2; k++)
-      trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds)
-                                  : (block == 512 ? wf_trace_fn<512>(k == 0, detail, trace_lds) : wf_trace_fn<256>(k == 0, detail, trace_lds));
-    if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_walk != (int)pairs || c->wf_occ_blocks[0] == 0) {
+      trace_fn[k] = block == 1024 ? wf_trace_fn<1024>(k == 0, detail, trace_lds, rayreg)
+                                  : (block == 512 ? wf_trace_fn<512>(k == 0, detail, trace_lds, rayreg) : wf_trace_fn<256>(k == 0, detail, trace_lds, rayreg));
+    if (c->wf_occ_dyn != dyn || c->wf_occ_detail != (int)detail || c->wf_occ_block != block || c->wf_occ_walk != (rayreg ? 2 : 0) || c->wf_occ_blocks[0] == 0) {
       for (int k = 0; k < 2; k++) {
         HIP_TRY(c, hipFuncSetAttribute(trace_fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         int per_cu = 0;
@@ -1705,9 +1715,12 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
       c->wf_occ_dyn = dyn;
       c->wf_occ_detail = (int)detail;
       c->wf_occ_block = block;
-      c->wf_occ_walk = (int)pairs;
+      c->wf_occ_walk = rayreg ? 2 : 0;
     }
   }
+  if (getenv("MI355RT_DEBUG_SHAPE"))
+    fprintf(stderr, "[mi355rt] trace kernels: %s walk, %d threads per workgroup, %zu bytes of LDS, resident workgroups per CU: any-hit %d, closest-hit %d\n",
+            pairs ? "pair" : "node", block, dyn, c->wf_occ_blocks[0], c->wf_occ_blocks[1]);
   uint32_t nn = pairs ? c->n_pairs : c->n_nodes, nt = c->n_tris, ni = c->n_instances;
   EventPair* ev = next_events(c, RT_TIMER_PATHTRACE);
   if (ev) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
@@ -1727,7 +1740,11 @@ static int launch_wavefront(rt_ctx* c, const DevScene& S, const DevFrame& F, con
     }
     if (evs) HIP_TRY(c, hipEventRecord(evs->b, c->stream));
     for (int k = 0; k < 2; k++) {
-      uint32_t blocks = (uint32_t)c->wf_occ_blocks[k] * (uint32_t)c->num_cus;
+      // resident workgroups: what fits (registers, LDS; since round 4 the node-walk kernels leave room for a seventh wave per
+      // SIMD), or MI355RT_WF_BLOCKS_PER_CU
+      uint32_t per_cu = (uint32_t)c->wf_occ_blocks[k];
+      if (c->wf_blocks_per_cu > 0 && per_cu > (uint32_t)c->wf_blocks_per_cu) per_cu = (uint32_t)c->wf_blocks_per_cu;
+      uint32_t blocks = per_cu * (uint32_t)c->num_cus;
       const uint32_t max_useful = (uint32_t)std::min<size_t>((items + (size_t)block - 1) / (size_t)block, (size_t)0x7fffffff);
       if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
       DevScene Sa = S;
