@@ -288,16 +288,17 @@ template <bool COUNT, bool LDS>
 __device__ __forceinline__ bool pw_flush(const PairMem& M, const f4* lds, const WaveWork& W, PairLane& s, uint32_t& n_tris) {
   const uint32_t lane = threadIdx.x & 63u;
   const bool waiting = s.state == PW_WAIT;
-  const unsigned long long smask = __ballot(pw_busy(s) && !waiting);
-  const unsigned long long wmask = __ballot(waiting);
-  if ((smask | wmask) == 0ull) return false;
-  if (wmask == 0ull) return true;
+  const unsigned long long wmask = __builtin_amdgcn_ballot_w64(waiting);
+  if (wmask == 0ull) return __builtin_amdgcn_ballot_w64(pw_busy(s)) != 0ull;
+  // due when RT_FLUSH_LANES lanes wait (k_traverse.hip.h), or nobody can produce more items without a flush
+  const unsigned long long pmask = __builtin_amdgcn_ballot_w64(pw_can_step(s) || s.state == PW_ENTER);
+  const uint32_t n_wait = pmask != 0ull ? (uint32_t)__builtin_popcountll(wmask) : 64u;
+  if (n_wait < RT_FLUSH_LANES) return true;
   const uint32_t cnt = waiting ? (s.leaf & 7u) : 0u;
-  const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+  const unsigned long long b0 = __builtin_amdgcn_ballot_w64((cnt & 1u) != 0u), b1 = __builtin_amdgcn_ballot_w64((cnt & 2u) != 0u),
+                           b2 = __builtin_amdgcn_ballot_w64((cnt & 4u) != 0u);
   const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
                          4u * (uint32_t)__builtin_popcountll(b2);
-  // wait for more items only while somebody can still produce them without a flush
-  if (total < RT_FLUSH_ITEMS && __ballot(pw_can_step(s) || s.state == PW_ENTER) != 0ull) return true;
   const uint32_t excl =
       __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
       2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
@@ -310,18 +311,22 @@ __device__ __forceinline__ bool pw_flush(const PairMem& M, const f4* lds, const 
     W.rays[2 * lane] = ra;
     W.rays[2 * lane + 1] = rb;
     W.res[lane] = ~0ull;
-    const uint32_t tag = lane << 26;
-#pragma unroll
-    for (uint32_t i = 0; i < 4u; i++)
-      if (i < cnt) W.items[excl + i] = tag | (first + i);
+    // four unconditional ordered stores, the highest slot first (trav_flush, k_traverse.hip.h, has the argument)
+    const rt_lptr32_ordered it = (rt_lptr32_ordered)(W.items + excl);
+    const uint32_t word = (lane << 26) | first;
+    it[3] = word + 3u;
+    it[2] = word + 2u;
+    it[1] = word + 1u;
+    it[0] = word;
   }
   // leaves of the reference's builder hold <= 4 triangles (blas.rs:99); only its fallback leaves hold 5-7
   if ((b2 & (b0 | b1)) != 0ull) {
     if (waiting) {
-      const uint32_t tag = lane << 26;
+      const rt_lptr32_ordered it = (rt_lptr32_ordered)(W.items + excl);
+      const uint32_t word = (lane << 26) | first;
 #pragma unroll
       for (uint32_t i = 4; i < 7u; i++)
-        if (i < cnt) W.items[excl + i] = tag | (first + i);
+        if (i < cnt) it[i] = word + i;
     }
   }
   __builtin_amdgcn_wave_barrier();
