@@ -496,12 +496,14 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
   const rt3 cam_v = rt3_make(U.camera.vertical[0], U.camera.vertical[1], U.camera.vertical[2]);
   const float lens = U.camera.origin[3];
 
-  // wave-uniform work cursor: pixels [tile_pos, 64) of tile `tile` are still unassigned
-  uint32_t tile = 0xffffffffu, tile_pos = 64u;
+  // wave-uniform work cursor: pixels [tile_pos, 64) of the wave's tile are still unassigned; the tile's origin and frame are
+  // worked out once per ticket (two divisions by run-time values, 20 instructions each: not once per regenerated lane)
+  uint32_t tile_pos = 64u, tile_x0 = 0u, tile_y0 = 0u, tile_slot = 0u;
   bool work_left = true;
 
   PathState p;
   uint32_t item_slot = 0u;  // frame of the batch the lane's current (frame, pixel) item belongs to
+  uint32_t pixel_xy = 0u;   // x | y << 16 of p.pixel
   bool alive = false;       // lane owns a running path
   bool have_pixel = false;  // lane owns a pixel whose samples are not all done
   uint32_t cnt_ext = 0, cnt_shadow = 0, cnt_nodes = 0, cnt_tris = 0, cnt_shaded = 0;
@@ -535,7 +537,13 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
             work_left = false;
             break;
           }
-          tile = t;  // frame-major ticket: frame = t / n_tiles, tile = t % n_tiles
+          // frame-major ticket: frame = t / n_tiles, tile = t % n_tiles
+          tile_slot = t / n_tiles;
+          const uint32_t tile_in_frame = t - tile_slot * n_tiles;
+          uint32_t trow = tile_in_frame / tiles_x;
+          tile_x0 = (tile_in_frame - trow * tiles_x) * 8u;
+          if (F.own_period) trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
+          tile_y0 = trow * 8u;
           tile_pos = 0u;
         }
         // rank of this lane among the needy lanes
@@ -543,17 +551,15 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
             __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         const uint32_t slot = tile_pos + rank;
         if (need && slot < 64u) {
-          const uint32_t tile_in_frame = tile % n_tiles;
-          uint32_t trow = tile_in_frame / tiles_x;
-          if (F.own_period) trow = (trow / F.own_run) * F.own_period + F.own_first + (trow % F.own_run);
-          const uint32_t x = (tile_in_frame % tiles_x) * 8u + (slot & 7u);
-          const uint32_t y = trow * 8u + (slot >> 3);
+          const uint32_t x = tile_x0 + (slot & 7u);
+          const uint32_t y = tile_y0 + (slot >> 3);
           need = false;
           if (x < U.width && y < U.height && owns_row(F, y)) {
             have_pixel = true;
             p.pixel = y * U.width + x;
+            pixel_xy = x | (y << 16);   // width, height <= 65535: rt_resize refuses more
             p.sample = 0u;
-            item_slot = tile / n_tiles;
+            item_slot = tile_slot;
             p.col = rt3_splat(0.0f);
           }
         }
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace
     // (b) start the next sample of the owned pixel: camera ray + depth-0 surface from the G-buffer
     RT_LSTAT(6, !alive && have_pixel);
     if (!alive && have_pixel) {
-      const uint32_t x = p.pixel % U.width, y = p.pixel / U.width;
+      const uint32_t x = pixel_xy & 0xffffu, y = pixel_xy >> 16;
       const DevFrameSlot slot = slots[item_slot];
       p.rng = init_rng(p.pixel, slot.frame_count * F.spp + p.sample);
       rt3 off = rt3_splat(0.0f);

@@ -644,7 +644,8 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
   c->gbuf_slot = -1;
   c->spec.valid = false;
   c->spec.slots.clear();
-  if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
+  // 65535: the persistent kernel packs a pixel's x and y into one word (WebGPU's maxTextureDimension2D is 8192)
+  if (width == 0 || height == 0 || width > 65535u || height > 65535u || (uint64_t)width * height > (1ull << 28))
     return fail(c, RT_ERR_INVALID, "invalid screen size");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
