@@ -63,7 +63,11 @@ __device__ __forceinline__ uint32_t zero_or_big_key(float x) { return (bits_(x) 
 // is used when the mask is empty.
 typedef unsigned long long lanemask;
 __device__ __forceinline__ lanemask lanes(bool c) { return __builtin_amdgcn_ballot_w64(c); }
-__device__ __forceinline__ lanemask bad_not_normal(float x) { return lanes(__builtin_amdgcn_classf(x, RT_CLS_NOT_NORMAL)); }
+__device__ __forceinline__ bool not_normal_(float x) { return __builtin_amdgcn_classf(x, RT_CLS_NOT_NORMAL); }
+// A guard is ONE ballot of the OR of its per-lane conditions, used only as `!= 0`: the compiler then branches on the OR'ed
+// compare masks themselves (v_cmp ... ; s_or ; s_cbranch_vccnz).  A ballot per condition OR'ed as 64-bit numbers costs a
+// v_cndmask + v_cmp_ne round trip per v_cmp_class (the ballot of an fp-class test is not folded into the compare).
+__device__ __forceinline__ lanemask bad_not_normal(float x) { return lanes(not_normal_(x)); }
 // The fallback branch: the hint has to sit on the branch itself (inside a helper it is dropped before inlining), and the
 // first statement of the branch is a volatile asm.  Division and square root have no side effects, so without the asm the
 // optimiser "if-converts" the branch: it computes the short sequence AND the full expansion for every wave and selects
@@ -93,7 +97,7 @@ __device__ __forceinline__ void rcp3(float x0, float x1, float x2, float& r0, fl
   r0 = rcp_seq(x0, a0);
   r1 = rcp_seq(x1, a1);
   r2 = rcp_seq(x2, a2);
-  RT_IEEE_IF_ANY(bad_not_normal(a0) | bad_not_normal(a1) | bad_not_normal(a2)) {
+  RT_IEEE_IF_ANY(lanes(not_normal_(a0) | not_normal_(a1) | not_normal_(a2))) {
     RT_IEEE_COLD();
     r0 = 1.0f / x0;
     r1 = 1.0f / x1;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void rcp3(float x0, float x1, float x2, float& r0, fl
 
 // ------------------------------------------------------------------------------------- sqrt(x), 1 / sqrt(x)
 __device__ __forceinline__ bool sqrt_guard(float x) { return x > RT_IEEE_LO && x < __builtin_inff(); }
-__device__ __forceinline__ lanemask sqrt_bad(float x) { return lanes(!(x > RT_IEEE_LO)) | lanes(!(x < __builtin_inff())); }
+__device__ __forceinline__ bool sqrt_bad_(float x) { return !(x > RT_IEEE_LO) | !(x < __builtin_inff()); }
 __device__ __forceinline__ float sqrt_seq(float x) {
   const float y = __builtin_amdgcn_rsqf(x);
   const float g = x * y;
@@ -117,7 +121,7 @@ __device__ __forceinline__ float sqrt(float x) {
   const float s = sqrt_seq(x);
   const bool zero = x == 0.0f;
   float r = zero ? x : s;
-  RT_IEEE_IF_ANY(sqrt_bad(x) & ~lanes(zero)) {
+  RT_IEEE_IF_ANY(lanes(sqrt_bad_(x) & !zero)) {
     RT_IEEE_COLD();
     r = __builtin_sqrtf(x);
   }
@@ -131,7 +135,7 @@ __device__ __forceinline__ float rsqrt_seq(float x) {
 }
 __device__ __forceinline__ float rsqrt(float x) {
   float y = rsqrt_seq(x);
-  RT_IEEE_IF_ANY(sqrt_bad(x)) {
+  RT_IEEE_IF_ANY(lanes(sqrt_bad_(x))) {
     RT_IEEE_COLD();
     y = 1.0f / __builtin_sqrtf(x);
   }
@@ -152,7 +156,7 @@ __device__ __forceinline__ float div_seq(float a, float b) {
 __device__ __forceinline__ bool div_guard(float q, float a) { return normal_(q) && __builtin_fabsf(a) > RT_IEEE_LO; }
 __device__ __forceinline__ float div(float a, float b) {
   float q = div_seq(a, b);
-  RT_IEEE_IF_ANY(bad_not_normal(q) | lanes(!(__builtin_fabsf(a) > RT_IEEE_LO))) {
+  RT_IEEE_IF_ANY(lanes(not_normal_(q) | !(__builtin_fabsf(a) > RT_IEEE_LO))) {
     RT_IEEE_COLD();
     q = a / b;
   }
@@ -166,7 +170,7 @@ __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, floa
   q1 = div_step(a1, b, y);
   q2 = div_step(a2, b, y);
   const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a0), __builtin_fabsf(a1)), __builtin_fabsf(a2));
-  RT_IEEE_IF_ANY(bad_not_normal(q0) | bad_not_normal(q1) | bad_not_normal(q2) | lanes(!(amin > RT_IEEE_LO))) {
+  RT_IEEE_IF_ANY(lanes(not_normal_(q0) | not_normal_(q1) | not_normal_(q2) | !(amin > RT_IEEE_LO))) {
     RT_IEEE_COLD();
     q0 = a0 / b;
     q1 = a1 / b;
@@ -194,8 +198,8 @@ __device__ __forceinline__ void div3z(float a0, float a1, float a2, float b, flo
   q1 = divz_step(a1, b, y);
   q2 = divz_step(a2, b, y);
   const float ya = __builtin_fabsf(y0);
-  RT_IEEE_IF_ANY(lanes(min3u_(zero_or_big_key(a0), zero_or_big_key(a1), zero_or_big_key(a2)) < RT_IEEE_KEY_LO) |
-                 lanes(!(max3abs_(a0, a1, a2) < RT_IEEE_HI)) | lanes(!(ya >= 1.4901161193847656e-8f)) | lanes(!(ya <= 67108864.0f))) {
+  RT_IEEE_IF_ANY(lanes((min3u_(zero_or_big_key(a0), zero_or_big_key(a1), zero_or_big_key(a2)) < RT_IEEE_KEY_LO) |
+                       !(max3abs_(a0, a1, a2) < RT_IEEE_HI) | !(ya >= 1.4901161193847656e-8f) | !(ya <= 67108864.0f))) {
     RT_IEEE_COLD();
     q0 = a0 / b;
     q1 = a1 / b;

@@ -232,13 +232,14 @@ __device__ __forceinline__ void trav_begin(Trav& s, bool active, uint32_t blas_b
 #endif
 }
 
-// the walk ran off its array: leave the instance (back to the world-space ray and the TLAS cursor), or finish.  Behind
-// wave-uniform tests: the six selects that restore the ray only run when some lane really goes back to a TLAS node (as a
-// per-lane branch the ray's registers were copied out and back on every trip to merge the two paths).
+// the walk ran off its array: leave the instance (back to the world-space ray and the TLAS cursor), or finish.  Behind a
+// wave-uniform test (one compare and a branch per step when nobody is at an end).
 __device__ __forceinline__ void trav_leave(Trav& s) {
   const bool at_end = s.curr == RT_CURR_END;
   if (__builtin_amdgcn_ballot_w64(at_end) != 0ull) {
     const bool leave = at_end & (s.tlas_next < RT_TLAS_NONE);   // inside an instance whose TLAS leaf has a successor
+    // the six selects that restore the ray sit behind a second wave-uniform test (as a per-lane branch the compiler
+    // predicates them: nine moves whenever some lane is at an end, which in a one-instance scene is never a way back)
     if (__builtin_amdgcn_ballot_w64(leave) != 0ull) {
       s.inv_d.x = leave ? s.rw.inv_d.x : s.inv_d.x; s.inv_d.y = leave ? s.rw.inv_d.y : s.inv_d.y;
       s.inv_d.z = leave ? s.rw.inv_d.z : s.inv_d.z;
@@ -250,15 +251,12 @@ __device__ __forceinline__ void trav_leave(Trav& s) {
   }
 }
 
-// instance entry of one lane: the object-space ray (its origin and direction go to the lane's slot of W.rays, where the
-// triangle tests of this instance's leaves will read them; nothing of an earlier instance is still queued — a lane waits at
-// every leaf until its tests are done), returns the BLAS root
 // Where the origin and direction of the instance-space ray go: to the lane's slot of W.rays once, at instance entry (the walk
 // then carries six registers less and a flush writes 4 bytes per waiting lane instead of 32), or with every flush.
 // Measured on MI355X (ms per 32 frames, at entry / with every flush): Cornell (LDS mode) 21.1 / 21.3; in the trace kernels
 // instanced x1000 72.4 / 75.7 but glass blob 4K 306.2 / 292.1 — at 5, 6, 7 or 8 resident workgroups per CU alike, and with
 // the flush itself 40 % cheaper under section stamps (tools/exp/ab_sections.sh); the cause is not established.  So both forms
-// are compiled for the trace kernels and the host picks by scene (rt_api.hip: one instance = registers).
+// are compiled for the trace kernels and the host picks by scene (rt_api.hip: many nodes per instance = registers).
 template <int MODE>
 __device__ __forceinline__ constexpr bool trav_post_at_entry() { return MODE != RT_TRAV_MIXED_RAYREG; }
 template <int MODE>
