@@ -79,7 +79,7 @@ def gather_calibration():
     """Rows of profiles/r03_gather_peak.txt (tools/gather_peak.hip on one MI355X): G lane-steps/s of dependent divergent
     gathers of one 32-byte record (2 x dwordx4) per step with ALL 64 lanes of every wave active, 6 workgroups per CU — the
     full-wave rate; the lanes a trace kernel leaves idle are reported as a loss term of their own (lane_utilization)."""
-    for name in ("r03_gather_peak.txt", "r02_gather_peak.txt"):
+    for name in ("r04_gather_peak.txt", "r03_gather_peak.txt", "r02_gather_peak.txt"):
         path = os.path.join(REPO, "profiles", name)
         out = {}
         try:

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 evidence of a round (run on the GPU box via gpurun; HEAD=<commit> in the environment names the code state,
 # RTAG=<rNN> the file prefix under profiles/).  One counter set per run (never --pmc together with other trace domains).
-# usage: RTAG=r03 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|bench|big|glass|world|calib|scene <name>|all]
+# usage: RTAG=r04 HEAD=<commit> bash tools/make_profiles_round.sh [cornell|bench|big|glass|world|calib|scene <name>|all]
 R=$GRAFT_REPO_ROOT
 WHAT=${1:-all}
-RTAG=${RTAG:-r03}
+RTAG=${RTAG:-r04}
 export RTAG
 OUT=$R/gpurun_out/profiles_$RTAG
 mkdir -p $OUT

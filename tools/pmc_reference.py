@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webgpu_raytracer_amd as _W  # noqa: E402  (the hash of the kernel sources the counters were collected from)
 
 d, commit = sys.argv[1], sys.argv[2]
-TAG = os.environ.get("RTAG", "r03")
+TAG = os.environ.get("RTAG", "r04")
 out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_reference.json")
 
 
@@ -48,6 +48,12 @@ if pt:
         for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):
             if pt.get(k):
                 entry["frac_of_wave_cycles_" + k[3:].lower()] = round(pt[k] / pt["SQ_WAVE_CYCLES"], 4)
+    if pt.get("SQ_WAVE_CYCLES") and pt.get("SQ_ACTIVE_INST_VALU") and pt.get("SQ_WAVES") and pt.get("SQ_BUSY_CYCLES"):
+        # VALU-pipe busy: wave-cycles with a vector instruction in flight per wave-cycle, times the waves resident on a SIMD
+        # (the persistent kernel keeps 4 there from start to end) = vector instructions in flight per SIMD cycle
+        entry["valu_busy_per_simd"] = round(4.0 * pt["SQ_ACTIVE_INST_VALU"] / pt["SQ_WAVE_CYCLES"], 4)
+        entry["valu_busy_note"] = ("4 resident waves x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: vector instructions in flight per SIMD "
+                                   "cycle; >= 1 means the VALU pipe of a SIMD is never idle for lack of a ready instruction")
     if pt.get("SQ_LDS_BANK_CONFLICT") and pt.get("SQ_ACTIVE_INST_LDS"):
         entry["lds_bank_conflict_frac_of_lds_cycles"] = round(pt["SQ_LDS_BANK_CONFLICT"] / pt["SQ_ACTIVE_INST_LDS"], 4)
     if pt.get("FETCH_SIZE") is not None and pt.get("WRITE_SIZE") is not None:
