@@ -420,11 +420,14 @@ __device__ __forceinline__ uint32_t trav_stage_mixed(TravMem& M, f4* lds, uint32
 
 // Occupancy: the LDS-resident form is latency bound at 4 waves/SIMD (registers), the global-memory form gains ~11 %
 // from 6 waves/SIMD even with the spills that costs (measured on MI355X).
+#ifndef RT_PT_LDS_WAVES
+#define RT_PT_LDS_WAVES 4      // waves per SIMD of the LDS-resident form (128 VGPRs)
+#endif
 #ifndef RT_PT_GLOBAL_WAVES
 #define RT_PT_GLOBAL_WAVES 6   // workgroups of 4 waves per CU = waves per SIMD of the global-memory form (tools/SWEEPS.md)
 #endif
 template <bool DETAIL, bool LDS>
-__global__ __launch_bounds__(256, LDS ? 4 : RT_PT_GLOBAL_WAVES) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
+__global__ __launch_bounds__(256, LDS ? RT_PT_LDS_WAVES : RT_PT_GLOBAL_WAVES) void k_pathtrace_persistent(DevScene Sg, DevFrame F, rt_scene_uniforms U,
                                                               uint32_t* __restrict__ ticket, uint32_t n_nodes_total,
                                                               uint32_t n_tris_total, uint32_t n_inst_total,
                                                               uint32_t n_verts_total,
