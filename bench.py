@@ -554,6 +554,25 @@ def main():
                     roof[k] = {"value": pt[k], "source": src}
             if pt.get("measured_issue_peak_Tlane"):
                 roof["frac_of_measured_issue_peak"] = round(roof["achieved"] / pt["measured_issue_peak_Tlane"], 4)
+            if "valu_busy_per_simd" in pt:
+                roof["valu_busy_per_simd"] = {"value": pt["valu_busy_per_simd"], "note": pt.get("valu_busy_note"), "source": src}
+            # `achieved` counts the vector lane-instructions the kernel EXECUTES for its rays, so a round that removes
+            # instructions lowers it while the image gets faster.  The same rays cost round 3's build 656.4 G lane-instructions
+            # per 32-frame launch (profiles/r03_cornell_pmc.json); that stream over this build's launch time is the
+            # like-for-like figure.
+            try:
+                r3 = json.load(open(os.path.join(REPO, "profiles", "r03_cornell_pmc.json")))
+                r3k = [v for k, v in r3.items() if "k_pathtrace_persistent" in k][0]
+                r3_lane = float(r3k["SQ_THREAD_CYCLES_VALU"]) * scale
+                roof["same_rays_comparison"] = {
+                    "r03_lane_instr_per_launch": r3_lane, "r03_insts_valu_per_launch": float(r3k["SQ_INSTS_VALU"]) * scale,
+                    "r03_insts_salu_per_launch": float(r3k["SQ_INSTS_SALU"]) * scale,
+                    "this_build_over_r03_lane_instr": round(lane / r3_lane, 4),
+                    "frac_at_r03_instruction_stream": round(r3_lane / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TLANE, 4),
+                    "note": "round 3: 0.369 at 22.63 ms per launch; the rays, their hits and every counter of the image are unchanged",
+                    "source": "profiles/r03_cornell_pmc.json (SQ_THREAD_CYCLES_VALU) / this run's launch time"}
+            except (OSError, ValueError, KeyError, IndexError):
+                pass
             ic = issue_calibration()
             if ic and pt.get("insts_valu_per_launch") and pt.get("insts_salu_per_launch") and pt.get("effective_clock_GHz"):
                 # Round 3 called the kernel "issue-bound at 0.79" against span-derived rates that wall clock does not confirm.
