@@ -377,20 +377,5 @@ __device__ __forceinline__ void pw_start(const PairMem& M, PairLane& s, bool act
                   M.troot.word, M.troot.hi[0], M.troot.hi[1], M.troot.hi[2], n_nodes);
 }
 
-// the whole walk of one wave's rays (persistent kernel): every lane brings one ray
-template <bool COUNT, bool LDS>
-__device__ __forceinline__ void pw_traverse(const PairMem& M, const f4* lds, f4* wave_lds, const WaveWork& W, LdsStack& stk,
-                                            PairLane& s, uint32_t& n_nodes, uint32_t& n_tris) {
-  for (;;) {
-#ifdef RT_PW_STAMPS
-    unsigned long long unused_cyc[6] = {0, 0, 0, 0, 0, 0};
-    pw_trip<COUNT, LDS, RT_PW_STEPS_PER_TRIP>(M, lds, wave_lds, stk, s, n_nodes, unused_cyc);
-#else
-    pw_trip<COUNT, LDS, RT_PW_STEPS_PER_TRIP>(M, lds, wave_lds, stk, s, n_nodes);
-#endif
-    if (!pw_flush<COUNT, LDS>(M, lds, W, s, n_tris)) break;
-  }
-}
-
 }  // namespace rtk
 #endif
