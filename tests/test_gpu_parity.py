@@ -495,6 +495,27 @@ def test_kernel_forms_agree_bitwise(W):
             assert ref[2] == got[2]
 
 
+def test_read_gbuffer_after_resize_reads_the_new_planes(W, gpu_renderer):
+    """Lookahead keeps pointers to the G-buffer planes of the batch it traced; rt_resize frees them.  A readGBuffer() between
+    the resize (to a LARGER screen: a stale pointer would be read out of bounds) and the next compute() must read the fresh,
+    zero-initialised planes of the new size (ResourceManager.ts:97-142), as without lookahead."""
+    b = pu.bridge_for(W, "cornell")
+    r = gpu_renderer
+    r.buildPipeline(4, 1)
+    W.upload_scene(r, b, 48, 32)
+    r.setLookahead(8)
+    r.compute(1)
+    r.compute(2)        # served from the frames traced ahead: the G-buffer of this frame lives in a batch plane
+    r.sync()
+    assert r.readGBuffer()[2].min() < 1.0          # something was hit
+    r.updateScreenSize(160, 120)
+    alb, nid, dep = r.readGBuffer()
+    assert alb.shape == (120, 160, 4) and not alb.any() and not nid.any() and not dep.any()
+    r.compute(1)        # and the renderer goes on at the new size
+    r.sync()
+    assert r.readGBuffer()[2].shape == (120, 160) and r.readGBuffer()[2].min() < 1.0
+
+
 def test_malformed_scene_arrays_are_refused_not_followed(W, gpu_renderer):
     """WebGPU's robust buffer access keeps the reference alive on a bad index; a HIP kernel would fault or spin. Every
     index the kernels follow is checked once per upload (k_validate_scene) and compute() fails with the reason."""
