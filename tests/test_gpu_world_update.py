@@ -210,6 +210,33 @@ def test_descriptions_the_device_path_refuses(W):
     rc, why = call(frame(1007, [geometry()], np.stack([instance(0), instance(0)])))
     assert rc >= 0, why
     assert len(r.worldRead("tlas")) // 8 == 3 and len(r.worldRead("instances")) // 36 == 2
+    # ---- the per-call skin arguments are checked against the static description on EVERY call (round 4)
+    joints[:, 0] = 0
+    weights[:, 0] = 1.0
+    mats = np.tile(np.eye(4, dtype=f32).reshape(-1), 2)                       # two joints, identity
+
+    def skinned_frame(epoch, n_skins, first):
+        g = geometry()
+        g.skin = 0
+        fr, arr = frame(epoch, [g], np.stack([instance(0)]))
+        fr.n_skins = n_skins
+        keep = np.array(first, np.uint32) if first is not None else None
+        fr.skin_first = keep.ctypes.data_as(up) if keep is not None else None
+        fr.joint_mats = mats.ctypes.data_as(fp)
+        return fr, arr, keep
+
+    rc, why = call(skinned_frame(2001, 1, [0, 2]))
+    assert rc >= 0, why
+    rc, why = call(skinned_frame(2001, 0, None))                              # fewer skins under the same static_epoch
+    assert rc < 0 and "number of skins changed" in why
+    rc, why = call(skinned_frame(2001, 1, None))
+    assert rc < 0 and "null skin table" in why
+    rc, why = call(skinned_frame(2001, 1, [1, 2]))
+    assert rc < 0 and "does not start at joint 0" in why
+    rc, why = call(skinned_frame(2002, 2, [0, 2, 1]))
+    assert rc < 0 and "not non-decreasing" in why
+    rc, why = call(skinned_frame(2003, 1, [0, 2]))                            # and a good frame is taken afterwards
+    assert rc >= 0, why
     r.destroy()
 
 
