@@ -123,18 +123,38 @@ def build_tex(force=False):
     return TEX_LIB
 
 
+RT_FLAGS_SIDECAR = RT_LIB + ".flags"   # the extra compiler flags the library in the tree was built with ("" = the product build)
+
+
+def _rt_flags_on_disk():
+    try:
+        return open(RT_FLAGS_SIDECAR).read()
+    except OSError:
+        return ""
+
+
 def build_rt(force=False, extra_flags=()):
+    """The HIP renderer.  extra_flags: a VARIANT build (sweeps, diagnostic stamps).  The flags of the library on disk are kept
+    in a sidecar file, so a variant library is never taken for the product one: a call that asks for other flags than the
+    library was built with rebuilds it, however new the file is."""
     src = os.path.join(CSRC, "rt_api.hip")
     deps = _glob_sources(CSRC, (".hip", ".h", ".hpp")) + _headers()
-    if not force and _newer(RT_LIB, deps):
+    want = " ".join(extra_flags)
+
+    def fresh():
+        return _newer(RT_LIB, deps) and _rt_flags_on_disk() == want
+
+    if not force and fresh():
         return RT_LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: the HIP renderer cannot be built" % HIPCC)
     with _build_lock():
-        if not force and _newer(RT_LIB, deps):
+        if not force and fresh():
             return RT_LIB
         cmd = [HIPCC] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-o", RT_LIB, src]
         _compile(cmd, RT_LIB)
+        with open(RT_FLAGS_SIDECAR, "w") as f:
+            f.write(want)
     return RT_LIB
 
 
