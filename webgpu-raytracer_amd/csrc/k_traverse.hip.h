@@ -314,10 +314,19 @@ __device__ __forceinline__ void trav_node(const TravMem& M, const f4* lds, const
   s.curr = got_leaf ? RT_CURR_IDLE : next;
 }
 
+// LDS mode: lanes that ran off their array are dealt with once per trip (0) or before every step (1).  A lane at an end does
+// not step anyway (RT_CURR_END is no node); looking for such lanes before every step cost 7 of the step's 49 instructions —
+// in most steps of a walk some lane is just ending.  Once per trip a lane that leaves an instance mid-trip idles for up to
+// STEPS - 1 steps; per ray the sequence of nodes and bounds is the same either way.
+#ifndef RT_LEAVE_PER_STEP
+#define RT_LEAVE_PER_STEP 0
+#endif
 // one node step for every stepping lane; select-based, two branches only
 template <bool COUNT, int MODE>
 __device__ __forceinline__ void trav_step(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s, uint32_t& n_nodes) {
+#if RT_LEAVE_PER_STEP
   trav_leave(s);
+#endif
 #ifdef RT_LANE_STATS
   RT_LSTAT(s.stat_kind, trav_stepping(s));
 #endif
@@ -389,6 +398,9 @@ __device__ __forceinline__ void trav_trip(const TravMem& M, const f4* lds, const
   if (MODE == RT_TRAV_LDS) {
 #pragma unroll
     for (int k = 0; k < STEPS; k++) trav_step<COUNT, MODE>(M, lds, W, s, n_nodes);
+#if !RT_LEAVE_PER_STEP
+    trav_leave(s);   // before the look at the queues, which must see a finished lane as idle
+#endif
   } else {
     trav_trip_mixed<COUNT, MODE, STEPS>(M, lds, W, s, n_nodes);
   }
