@@ -293,14 +293,29 @@ template <bool COUNT, int MODE, bool DEFER>
 __device__ __forceinline__ void trav_node(const TravMem& M, const f4* lds, const WaveWork& W, Trav& s, f4 lo, f4 hi,
                                           uint32_t& n_nodes) {
   if (COUNT) n_nodes++;
-  const bool hit = hit_box4(lo, hi, s.inv_d, s.o_inv_d, RT_T_MIN, s.closest);
   const uint32_t data = rt_f2u(hi.w);
+#ifndef RT_NODE_BOOLS
+  // The three facts about the lane (box hit, inner node, walking the TLAS) as lane masks, combined by scalar and / andn2 and
+  // handed back as conditions (inverse ballot: no instruction).  Written as bools the compiler computes `!inner` with a
+  // second vector compare and `!in_tlas` with a scalar xor: two instructions more per step.
+  const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit_box4(lo, hi, s.inv_d, s.o_inv_d, RT_T_MIN, s.closest));
+  const unsigned long long im = __builtin_amdgcn_ballot_w64((int32_t)data < 0);           // RT_NODE_INNER is the sign bit
+  const unsigned long long tm = __builtin_amdgcn_ballot_w64(s.tlas_next == RT_TLAS_NONE);
+  const unsigned long long lm = hm & ~im;                                                  // a leaf whose box is hit
+  const bool hit_inner = __builtin_amdgcn_inverse_ballot_w64(hm & im);
+  const bool tlas_leaf = __builtin_amdgcn_inverse_ballot_w64(lm & tm);
+  const bool got_leaf = __builtin_amdgcn_inverse_ballot_w64(lm & ~tm);
+#else
+  const bool hit = hit_box4(lo, hi, s.inv_d, s.o_inv_d, RT_T_MIN, s.closest);
   const bool inner = (data & RT_NODE_INNER) != 0u;
   const bool leafhit = hit & !inner;
-  uint32_t next = (hit & inner) ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
+  const bool hit_inner = hit & inner;
   const bool in_tlas = s.tlas_next == RT_TLAS_NONE;
   const bool got_leaf = leafhit & !in_tlas;
-  if (leafhit & in_tlas) {  // TLAS leaf: enter the instance
+  const bool tlas_leaf = leafhit & in_tlas;
+#endif
+  uint32_t next = hit_inner ? (data & ~RT_NODE_INNER) : rt_f2u(lo.w);
+  if (tlas_leaf) {  // TLAS leaf: enter the instance
     s.cur_inst = data >> 3;
     s.tlas_next = next;
     if (DEFER) {
