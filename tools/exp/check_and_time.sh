@@ -1,3 +1,5 @@
+# The loop of a kernel change: product-build + counting parity tests, then ms per image / per 32 frames of the headline and the three large configs.
+# usage (GPU box): bash tools/exp/check_and_time.sh <tag>   -> gpurun_out/<tag>/{pytest.log,time.log}
 set -o pipefail
 O=gpurun_out/${1:-r04q}
 mkdir -p $O

@@ -1,4 +1,5 @@
-O=gpurun_out/r05h; mkdir -p $O
+# Single-frame dispatches of the large scenes: persistent global-memory form at 6 / 5 / 4 waves per SIMD, wavefront form at n = 1.
+O=gpurun_out/single_frame; mkdir -p $O
 for w in 6 5 4; do
   python -c "import webgpu_raytracer_amd._build as b; b.build_rt(force=True, extra_flags=['-DRT_PT_GLOBAL_WAVES=$w'])" > /dev/null 2>&1
   for sc in sponza_like instanced1000; do

@@ -1,11 +1,8 @@
-set -o pipefail
-mkdir -p gpurun_out/r04m
-O=gpurun_out/r04m
-timeout -k 10 900 python -m pytest tests/test_gpu_world_update.py -q -x -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -n 4 $O/pytest.log
-timeout -k 10 300 python - > $O/tlas_time.log 2>&1 <<'PY'
+#!/usr/bin/env python3
+"""k_tlas alone and the whole device update at 1 001 and 16 384 instances (rt_world_last_tlas_ms); bench.py world_update.tlas has the same."""
+
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import webgpu_raytracer_amd as pkg
 for sc in ("instanced1000", "instanced16384"):
     r = pkg.WebGPURenderer(0); r.buildPipeline(8, 1); r.setWorldStaticCache(False)
@@ -17,5 +14,3 @@ for sc in ("instanced1000", "instanced16384"):
         ta += r.worldLastMs(); tt += r.worldLastTlasMs()
     print(sc, len(b.instances)//36, "instances: k_tlas %.4f ms, whole device update %.4f ms" % (tt/10, ta/10))
     b.close(); r.destroy()
-PY
-cat $O/tlas_time.log | grep -v amdgpu.ids
